@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference -- test infrastructure.
+
+Runs only in the build container, where the reference checkout is mounted read-only at
+/root/reference.  It imports ``diffrend.numpy.renderer`` (and the reference's own model / scene
+loaders), renders each golden case and stores inputs + expected outputs as data.  Nothing of the
+reference's code is written anywhere; the GPU box never sees /root/reference.
+
+    python oracle/gen_golden.py            # (re)writes tests/golden/
+
+Cases: g1 demo scene, g2 demo + planes (all four primitive types), g3 basic.json,
+g4 halfbox_sphere_cube.json, g5 bunny.splat recipe, g6 bunny.obj mesh, g7 synthetic disc cloud,
+g8* quirk probes.  Geometry is rounded to fp32 *before* the reference renders it, so the expected
+outputs are for exactly the values the device arrays hold.
+"""
+import contextlib
+import copy
+import io
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("SRH_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle.golden_io import save_case  # noqa: E402
+from surf_renderer_amd import synthetic  # noqa: E402  (scene *data* builders only)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import diffrend.numpy.renderer as ref_np  # noqa: E402
+    import diffrend.model as ref_model  # noqa: E402
+    import diffrend.torch.render as ref_tch_render  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
+def ref_render(scene):
+    sc = copy.deepcopy(scene)
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        res = ref_np.render(sc)
+    return {k: np.array(res[k]) for k in ("image", "depth", "nearest")}
+
+
+def emit(name, scene, note):
+    out = ref_render(scene)
+    save_case(os.path.join(OUT, name + ".npz"), scene, out, note)
+    hit = np.isfinite(out["depth"]).mean()
+    print(f"{name:28s} {out['depth'].shape}  hit {hit:6.1%}  image max {out['image'].max():.4f}")
+
+
+def ref_json_scene(fname, width, height):
+    """Expanded scene via the reference's own JSON loader (torch/render.py:37-78)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc = ref_tch_render.load_scene(os.path.join(REF, "scenes", fname))
+    tri = sc["objects"]["triangle"]
+    sc["objects"]["triangle"] = {"face": f32(tri["face"]), "normal": f32(tri["normal"]),
+                                 "material_idx": np.asarray(tri["material_idx"]).astype(np.int64)}
+    sc["camera"]["viewport"] = [0, 0, width, height]
+    lights = sc["lights"]
+    sc["lights"] = {"pos": f32(lights["pos"]), "color_idx": np.asarray(lights["color_idx"], dtype=np.int64)}
+    sc["colors"] = f32(sc["colors"])
+    sc["materials"] = {"albedo": f32(sc["materials"]["albedo"])}
+    sc["tonemap"] = {"type": "gamma", "gamma": float(np.ravel(sc["tonemap"]["gamma"])[0])}
+    for k in ("file-format", "glsl"):
+        sc.pop(k, None)
+    sc["camera"].pop("proj_type", None)
+    return sc
+
+
+def strip(sc):
+    sc = copy.deepcopy(sc)
+    sc["camera"].pop("proj_type", None)
+    sc["lights"] = {"pos": sc["lights"]["pos"], "color_idx": sc["lights"]["color_idx"]}
+    sc["materials"] = {"albedo": sc["materials"]["albedo"]}
+    return sc
+
+
+def probe_base(w=25, h=25, near=0.1):
+    return {
+        "camera": {"viewport": [0, 0, w, h], "fovy": float(np.deg2rad(60.0)), "focal_length": 1.0,
+                   "eye": [0.0, 0.0, 5.0, 1.0], "up": [0.0, 1.0, 0.0, 0.0], "at": [0.0, 0.0, 0.0, 1.0],
+                   "near": near, "far": 100.0},
+        "lights": {"pos": f32([[3, 4, 6, 1], [-5, 1, 2, 1]]), "color_idx": np.array([1, 2])},
+        "colors": f32([[0, 0, 0], [.9, .8, .7], [.2, .3, .9]]),
+        "materials": {"albedo": f32([[.5, .5, .5], [.9, .2, .2], [.2, .9, .2]])},
+        "objects": {},
+        "tonemap": {"type": "gamma", "gamma": 0.8},
+    }
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    emit("g1_demo_64x48", strip(synthetic.demo_scene(64, 48)),
+         "numpy/renderer.py:299-358 demo scene, viewport shrunk to 64x48; non-orthogonal up (Q1)")
+    emit("g2_demo_planes_64x48", strip(synthetic.demo_scene(64, 48, with_planes=True)),
+         "demo scene + 2 planes + 4 lights: all four primitive types, dict order plane,disk,sphere,triangle")
+    emit("g3_basic_json_64x64", ref_json_scene("basic.json", 64, 64),
+         "scenes/basic.json via the reference loader; image is identically 0 (lights in the triangle plane)")
+    emit("g3_basic_json_128x128", ref_json_scene("basic.json", 128, 128), "BASELINE config 1")
+    emit("g4_halfbox_sphere_cube_64x64", ref_json_scene("halfbox_sphere_cube.json", 64, 64),
+         "scenes/halfbox_sphere_cube.json (978 triangles, 3 lights) via the reference loader")
+
+    # g5: bunny.splat with the test_scalability recipe (torch/test_optimization.py:626-655), geometry from
+    # the reference's load_model
+    with contextlib.redirect_stdout(io.StringIO()):
+        spl = ref_model.load_model(os.path.join(REF, "data", "bunny.splat"))
+    v = spl["v"]
+    v = (v - np.mean(v, axis=0)) / (v.max() - v.min())
+    m = v.shape[0]
+    g5 = strip(synthetic.splat_basic_scene(64, 64))
+    g5["camera"]["fovy"] = float(np.deg2rad(5.0))
+    g5["camera"]["focal_length"] = 2.0
+    g5["objects"] = {"disk": {"pos": f32(np.c_[v, np.ones(m)]), "normal": f32(np.c_[spl["vn"], np.zeros(m)]),
+                              "radius": f32(spl["r"].ravel() * 2), "material_idx": np.zeros(m, dtype=np.int64)}}
+    g5["materials"] = {"albedo": f32([[0.6, 0.6, 0.6]])}
+    emit("g5_bunny_splat_64x64", g5, "data/bunny.splat, test_scalability recipe (BASELINE config 2 at 64x64)")
+
+    # g6: bunny.obj triangles (torch/full_diff_renderer_demo.py:29-58), geometry from the reference's loaders
+    with contextlib.redirect_stdout(io.StringIO()):
+        obj = ref_model.load_model(os.path.join(REF, "data", "bunny.obj"))
+    vv = obj["v"]
+    obj["v"] = (vv - np.mean(vv, axis=0)) / max(np.max(vv, axis=0) - np.min(vv, axis=0))
+    spec = ref_model.obj_to_triangle_spec(obj)
+    g6 = strip(synthetic.splat_basic_scene(48, 48))
+    g6["camera"]["fovy"] = float(np.deg2rad(8.0))
+    g6["objects"] = {"triangle": {"face": f32(spec["face"]), "normal": f32(spec["normal"]),
+                                  "material_idx": np.zeros(spec["face"].shape[0], dtype=np.int64)}}
+    g6["materials"] = {"albedo": f32([[0.6, 0.6, 0.6]])}
+    emit("g6_bunny_mesh_48x48", g6, "data/bunny.obj as 4968 triangles (BASELINE config 4 at 48x48)")
+
+    emit("g7_disk_cloud_2000_r02_64x64", synthetic.disk_cloud_scene(2000, 64, 64, radius=0.02, seed=20240),
+         "config-5 generator, 2000 discs radius 0.02")
+    emit("g7_disk_cloud_3000_r08_64x64", synthetic.disk_cloud_scene(3000, 64, 64, radius=0.08, seed=7),
+         "config-5 generator, 3000 discs radius 0.08 (dense overlaps)")
+
+    # ---- g8 quirk probes --------------------------------------------------------------------------
+    s = probe_base()
+    s["objects"]["sphere"] = {"pos": f32([[0, 0, 9, 1], [1.5, 0.5, 0, 1]]), "radius": f32([2.0, 1.0]),
+                              "material_idx": np.array([1, 2])}
+    emit("g8a_sphere_behind_camera", s, "Q2: sphere behind the eye yields phantom hits at t = 1.0 (near = 0.1)")
+
+    s = probe_base()
+    s["objects"]["disk"] = {"pos": f32([[0.5, 0, 0, 1], [0, 0, 0, 1], [-0.5, 0.2, 0, 1]]),
+                            "normal": f32([[0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 2, 0]]),
+                            "radius": f32([1.5, 1.5, 1.2]), "material_idx": np.array([1, 2, 0])}
+    emit("g8b_coplanar_disks_tie", s, "Q6: coplanar overlapping discs -> exact ties, lowest index wins")
+
+    s = probe_base()
+    s["objects"]["plane"] = {"pos": f32([[0, 0, 0, 1]]), "normal": f32([[0, 0, 1, 0]]), "material_idx": np.array([1])}
+    s["lights"] = {"pos": f32([[0, 0, 0, 1], [2, 2, 3, 1]]), "color_idx": np.array([1, 2])}
+    emit("g8c_light_on_surface", s, "Q7: a light exactly at the centre pixel's hit point (|l| = 0 -> 1)")
+
+    s = probe_base()
+    s["objects"]["triangle"] = {"face": f32([[[-1, -1, 0, 1], [1, -1, 0, 1], [0, 1, 0, 1]],
+                                             [[-2, -2, -1, 1], [2, -2, -1, 1], [0, 2, -1, 1]],
+                                             [[-2, -2, -2, 1], [0, 2, -2, 1], [2, -2, -2, 1]]]),
+                                "normal": f32([[0, 0, 0, 0], [0, 0, 1, 0], [0, 0, 1, 0]]),
+                                "material_idx": np.array([1, 2, 1])}
+    emit("g8d_degenerate_triangle", s, "zero normal -> nan t, never hit; third triangle wound against its normal (Q9)")
+
+    s = probe_base()
+    s["objects"]["plane"] = {"pos": f32([[0, -1, 0, 1], [0.5, 0, 0, 1]]), "normal": f32([[0, 1, 0, 0], [1, 0, 0, 0]]),
+                             "material_idx": np.array([1, 2])}
+    emit("g8e_plane_parallel_to_rays", s, "planes parallel to the central row/column of rays: denom = 0 -> inf/nan")
+
+    s = probe_base()
+    s["objects"]["sphere"] = {"pos": f32([[0, 0, 4, 1]]), "radius": f32([3.0]), "material_idx": np.array([1])}
+    emit("g8f_camera_inside_sphere", s, "Q2: eye inside the sphere -> min(1.0, t2)")
+
+    s = probe_base(near=0.0)
+    s["objects"]["disk"] = {"pos": f32([[0, 0, 1, 1]]), "normal": f32([[0, 0, 1, 0]]), "radius": f32([1.0]),
+                            "material_idx": np.array([2])}
+    s["objects"]["sphere"] = {"pos": f32([[1.0, 0, 0, 1]]), "radius": f32([0.8]), "material_idx": np.array([1])}
+    emit("g8g_near_zero_sphere_miss", s, "near = 0: rays whose line misses the sphere get t = 0, which is then valid")
+
+    s = probe_base(w=1, h=1)
+    s["objects"]["disk"] = {"pos": f32([[-2, 2, 0, 1]]), "normal": f32([[0, 0, 1, 0]]), "radius": f32([3.0]),
+                            "material_idx": np.array([1])}
+    emit("g8h_viewport_1x1", s, "Q12: W = H = 1 -> the single sample sits at x = -1, y = +1")
+    s = probe_base(w=7, h=1)
+    s["objects"]["disk"] = {"pos": f32([[0, 2, 0, 1]]), "normal": f32([[0, 0.2, 1, 0]]), "radius": f32([3.0]),
+                            "material_idx": np.array([2])}
+    emit("g8i_viewport_7x1", s, "ragged viewport, one row")
+
+    s = strip(synthetic.demo_scene(40, 30))
+    s["camera"]["eye"] = np.array([0.3, 1.7, 9.1, 1.0])
+    s["camera"]["at"] = np.array([0.1, -0.2, 0.05, 1.0])
+    s["camera"]["up"] = np.array([0.1, 1.0, -0.05, 0.0])
+    s["objects"] = {k: s["objects"][k] for k in ("triangle", "sphere", "disk")}
+    emit("g8j_array_camera_reordered", s,
+         "ndarray-typed eye/at/up that are NOT fp32-representable (no float32 detour, Q11); dict order "
+         "triangle, sphere, disk")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""The CPU oracle (oracle/np_oracle.py) against every golden vector produced by the reference.
+
+This is what pins the oracle: the expected outputs in tests/golden/*.npz came from the unmodified
+``diffrend.numpy.renderer.render`` (oracle/gen_golden.py).  fp64 against fp64: image and depth must
+agree to 1e-12, ``nearest`` exactly, NaNs in the same places (g8f has one by construction).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, golden_cases
+from oracle import np_oracle
+from oracle.golden_io import load_case
+
+CASES = golden_cases()
+
+
+def test_golden_set_is_complete():
+    stems = {c.split("_")[0] for c in CASES}
+    assert {"g1", "g2", "g3", "g4", "g5", "g6", "g7"} <= stems
+    assert sum(c.startswith("g8") for c in CASES) >= 8
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [2048, 97])
+def test_oracle_matches_reference_output(case, tile):
+    if tile == 97 and case.startswith(("g4", "g5", "g6")):
+        pytest.skip("one tiling is enough for the large cases")
+    scene, want, _ = load_case(os.path.join(GOLDEN_DIR, case + ".npz"))
+    got = np_oracle.render(scene, tile=tile)
+    assert got["nearest"].dtype == np.int64
+    np.testing.assert_array_equal(got["nearest"], want["nearest"])
+    np.testing.assert_array_equal(np.isfinite(got["depth"]), np.isfinite(want["depth"]))
+    np.testing.assert_allclose(got["depth"], want["depth"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got["image"], want["image"], rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
+def test_oracle_row_window_equals_full_frame():
+    scene, want, _ = load_case(os.path.join(GOLDEN_DIR, "g2_demo_planes_64x48.npz"))
+    part = np_oracle.render(scene, rows=(10, 23))
+    np.testing.assert_array_equal(part["nearest"], want["nearest"][10:23])
+    np.testing.assert_allclose(part["depth"], want["depth"][10:23], rtol=1e-12)
+    np.testing.assert_allclose(part["image"], want["image"][10:23], rtol=1e-12, atol=1e-14)
+
+
+def test_oracle_fp32_mode_is_close():
+    scene, want, _ = load_case(os.path.join(GOLDEN_DIR, "g1_demo_64x48.npz"))
+    got = np_oracle.render(scene, dtype=np.float32)
+    same = got["nearest"] == want["nearest"]
+    assert same.mean() > 0.995
+    hit = same & np.isfinite(want["depth"])
+    np.testing.assert_allclose(got["depth"][hit], want["depth"][hit], rtol=2e-5)
+    np.testing.assert_allclose(got["image"][hit], want["image"][hit], atol=2e-4)
