@@ -1,0 +1,133 @@
+/*
+ * srh.h -- C ABI of the MI355X-native ("hip") backend for DiffRend's render(scene) hot path.
+ *
+ * The reference project (fmannan/surf_renderer) has no FFI for this path: each backend is a Python
+ * module exposing `render(scene) -> dict` (diffrend/numpy/renderer.py:204-272,
+ * diffrend/torch/renderer.py:136-355).  This header is the boundary a `--use hip` backend binds
+ * instead: one call per frame per GPU, plain pointers and sizes, no torch / numpy types.  The
+ * Python mirror of the reference interface lives in surf_renderer_amd/renderer.py and calls these
+ * entry points through ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - Every device buffer is allocated and freed by the caller.  The library keeps no device memory
+ *     and no global state between calls; all work is enqueued on the stream that is passed in and no
+ *     entry point synchronises.
+ *   - Arrays use the reference's layouts (docs/scene_description.md, numpy/renderer.py:299-358):
+ *     homogeneous 4-vectors, points w = 1, directions / normals w = 0, row-major, float32 on the
+ *     device; index arrays are int32.
+ *   - Primitive numbering is the reference's: segments in scene['objects'] dict order, running offset
+ *     (numpy/renderer.py:172-201).  The lowest global index wins exact depth ties (np.argmin, :223).
+ *   - Return value: 0 on success, a positive hipError_t, or a negative SRH_E_* code.  No C++ exception
+ *     crosses the boundary; srh_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef SRH_H
+#define SRH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRH_ABI_VERSION 1
+#define SRH_MAX_SEGMENTS 4
+#define SRH_MAX_LIGHTS 64
+
+/* primitive types: keys of scene['objects'] (numpy/renderer.py:133-137) */
+enum { SRH_PRIM_DISK = 0, SRH_PRIM_PLANE = 1, SRH_PRIM_SPHERE = 2, SRH_PRIM_TRIANGLE = 3 };
+
+/* error codes (negative; positive values are hipError_t) */
+enum {
+  SRH_OK = 0,
+  SRH_E_NULL = -1,        /* a required pointer is NULL */
+  SRH_E_RANGE = -2,       /* a count / row range / viewport is out of range */
+  SRH_E_TYPE = -3,        /* unknown primitive type or mode */
+  SRH_E_WORKSPACE = -4,   /* workspace too small or misaligned */
+  SRH_E_CAMERA = -5       /* degenerate camera (eye == at, zero up, w conventions violated) */
+};
+
+/* render modes (SrhParams.mode) -- all modes produce bit-identical outputs */
+enum {
+  SRH_MODE_AUTO = 0,      /* the fastest exact path */
+  SRH_MODE_EXACT = 1,     /* every (pixel, primitive) pair through the fp64 intersection (checker mode) */
+  SRH_MODE_FAST = 2       /* fp32 conservative reject per pair + fp64 confirmation of the survivors */
+};
+
+/* scene['camera'] (numpy/renderer.py:145-169, numpy/ops.py:88-115).  Host memory, float64.
+ * The caller applies the reference's float32 detour for list-typed at/up before filling this. */
+typedef struct SrhCamera {
+  double eye[4];          /* w must be 1 */
+  double at[4];
+  double up[4];           /* w must be 0 */
+  double fovy;            /* radians */
+  double focal_length;
+  double near_clip;       /* valid hit: near <= t <= far on Euclidean ray distance (:219) */
+  double far_clip;
+  int32_t viewport[4];    /* x0, y0, x1, y1; W = x1 - x0, H = y1 - y0 */
+} SrhCamera;
+
+/* one entry of scene['objects']: a batch of primitives of one type (device pointers) */
+typedef struct SrhSegment {
+  int32_t type;                 /* SRH_PRIM_* */
+  int32_t count;
+  const float* pos;             /* (count,4)   disk, plane, sphere */
+  const float* normal;          /* (count,4)   disk, plane, triangle (never recomputed from vertices, :107) */
+  const float* radius;          /* (count)     disk, sphere */
+  const float* face;            /* (count,3,4) triangle */
+  const int32_t* material_idx;  /* (count) */
+} SrhSegment;
+
+typedef struct SrhObjects {
+  int32_t n_segments;           /* <= SRH_MAX_SEGMENTS, scene['objects'] dict order */
+  SrhSegment seg[SRH_MAX_SEGMENTS];
+} SrhObjects;
+
+/* scene['lights'] + scene['colors'] (numpy/renderer.py:234-237) */
+typedef struct SrhLights {
+  int32_t n_lights;             /* <= SRH_MAX_LIGHTS */
+  int32_t n_colors;
+  const float* pos;             /* (n_lights,4) device */
+  const int32_t* color_idx;     /* (n_lights)   device, rows of `colors` */
+  const float* colors;          /* (n_colors,3) device */
+} SrhLights;
+
+/* scene['materials'] (numpy/renderer.py:245) */
+typedef struct SrhMaterials {
+  int32_t n_materials;
+  const float* albedo;          /* (n_materials,3) device */
+} SrhMaterials;
+
+typedef struct SrhParams {
+  int32_t row0, row1;           /* render image rows [row0,row1) of the camera's H rows; the output
+                                   buffers hold only those rows (multi-GPU row slabs) */
+  int32_t mode;                 /* SRH_MODE_* */
+  int32_t tonemap_gamma;        /* 1: image <- image ** gamma  (scene has a 'tonemap' entry, :262) */
+  double gamma;
+} SrhParams;
+
+int srh_abi_version(void);
+const char* srh_last_error(void);
+
+/* bytes of caller-provided device scratch needed for `objects` (per-frame primitive records).
+ * Returns 0 and sets srh_last_error on invalid input.  The buffer must be 256-byte aligned. */
+size_t srh_workspace_bytes(const SrhObjects* objects);
+
+/* replaces generate_rays (numpy/renderer.py:145-169): unit ray directions for rows [row0,row1),
+ * written as the reference returns them, ray_dir (4, n) row-major with n = (row1-row0)*W. */
+int srh_generate_rays(const SrhCamera* camera, int32_t row0, int32_t row1, float* ray_dir, void* stream);
+
+/* replaces render() (numpy/renderer.py:204-272): rays -> all-pairs intersection -> nearest valid hit ->
+ * Lambert shading over the point lights -> clip -> tonemap.
+ *   image   (rows, W, 3) float32
+ *   depth   (rows, W)    float32, +inf where nothing is hit (:228)
+ *   nearest (rows, W)    int32 global primitive index, 0 where nothing is hit (:223); may be NULL */
+int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                   const SrhMaterials* materials, const SrhParams* params,
+                   void* workspace, size_t workspace_bytes,
+                   float* image, float* depth, int32_t* nearest, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRH_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libsrh.so (the C ABI in include/srh.h).  Fails loudly when the library is
+missing or was built for a different ABI: there is no CPU fallback behind the hip backend."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+ABI_VERSION = 1
+MAX_SEGMENTS = 4
+MAX_LIGHTS = 64
+
+MODE_AUTO, MODE_EXACT, MODE_FAST = 0, 1, 2
+MODES = {"auto": MODE_AUTO, "exact": MODE_EXACT, "fast": MODE_FAST}
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class SrhCamera(C.Structure):
+    _fields_ = [("eye", C.c_double * 4), ("at", C.c_double * 4), ("up", C.c_double * 4),
+                ("fovy", C.c_double), ("focal_length", C.c_double),
+                ("near_clip", C.c_double), ("far_clip", C.c_double),
+                ("viewport", C.c_int32 * 4)]
+
+
+class SrhSegment(C.Structure):
+    _fields_ = [("type", C.c_int32), ("count", C.c_int32),
+                ("pos", C.c_void_p), ("normal", C.c_void_p), ("radius", C.c_void_p),
+                ("face", C.c_void_p), ("material_idx", C.c_void_p)]
+
+
+class SrhObjects(C.Structure):
+    _fields_ = [("n_segments", C.c_int32), ("seg", SrhSegment * MAX_SEGMENTS)]
+
+
+class SrhLights(C.Structure):
+    _fields_ = [("n_lights", C.c_int32), ("n_colors", C.c_int32),
+                ("pos", C.c_void_p), ("color_idx", C.c_void_p), ("colors", C.c_void_p)]
+
+
+class SrhMaterials(C.Structure):
+    _fields_ = [("n_materials", C.c_int32), ("albedo", C.c_void_p)]
+
+
+class SrhParams(C.Structure):
+    _fields_ = [("row0", C.c_int32), ("row1", C.c_int32), ("mode", C.c_int32),
+                ("tonemap_gamma", C.c_int32), ("gamma", C.c_double)]
+
+
+EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd")
+
+_lib: Optional[C.CDLL] = None
+
+
+class SrhError(RuntimeError):
+    """A libsrh entry point returned non-zero."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsrh error {code}: {message}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen libsrh.so (building it with hipcc first if it is absent and a toolchain exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing; run `python -m surf_renderer_amd.build`")
+        _build.build_lib()
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{path} does not export {name}")
+    lib.srh_abi_version.restype = C.c_int
+    lib.srh_last_error.restype = C.c_char_p
+    lib.srh_workspace_bytes.restype = C.c_size_t
+    lib.srh_workspace_bytes.argtypes = [C.POINTER(SrhObjects)]
+    lib.srh_generate_rays.restype = C.c_int
+    lib.srh_generate_rays.argtypes = [C.POINTER(SrhCamera), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.srh_render_fwd.restype = C.c_int
+    lib.srh_render_fwd.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
+                                   C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    got = lib.srh_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {got}, this package expects {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise SrhError(code, load().srh_last_error().decode("utf-8", "replace"))

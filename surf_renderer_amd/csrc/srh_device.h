@@ -1,0 +1,198 @@
+// Device-side data model and the fp64 "truth" functions of the hip render backend (gfx950 only).
+//
+// Everything that decides a pixel's value funnels through the functions in this header:
+//   pixel_ray()      -- generate_rays          (reference numpy/renderer.py:145-169)
+//   hit_*64()        -- ray_*_intersection     (reference numpy/renderer.py:9-130)
+//   shade_pixel()    -- fragment stage, clip, tonemap (reference numpy/renderer.py:234-263)
+// They mirror the reference's fp64 formulas term by term (the TU is compiled with
+// -ffp-contract=off so a*b+c is not fused behind our back); fp32 only appears when the three
+// outputs are stored.  Faster render modes may *skip* calling hit_*64 for pairs they can prove are
+// misses, but never replace it, which is why all modes are bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "srh.h"
+
+namespace srh {
+
+constexpr int kRec64Stride[4] = {8, 4, 4, 24};   // doubles per primitive record, by SRH_PRIM_*
+
+// One scene['objects'] entry as the kernels see it.
+struct SegDev {
+  int32_t type, count, first, pad;   // first = global index of the segment's first primitive
+  const double* rec64;               // per-frame records written by k_prep (layout below)
+  const float* rec32;                // per-frame fp32 reject records (FAST mode)
+  const float* pos;
+  const float* normal;
+  const float* radius;
+  const float* face;
+  const int32_t* mat;
+};
+
+// Per-frame constants, passed to kernels by value.
+struct FrameDev {
+  double o[3];                       // ray origin = eye[:3]
+  double bx[3], by[3], bz[3];        // camera basis columns of lookat_inv (x not unit in general, Q1)
+  double half_w, half_h, focal;      // w/2, h/2, focal_length
+  double step_x, step_y;             // linspace steps: 2/(W-1), -2/(H-1) (0 when the axis has 1 sample)
+  double near_clip, far_clip, gamma;
+  int32_t W, H, row0, row1;
+  int32_t nseg, total, nlights, ncolors, nmat, tonemap;
+  SegDev seg[SRH_MAX_SEGMENTS];
+  const float* lpos;
+  const int32_t* lcidx;
+  const float* colors;
+  const float* albedo;
+};
+
+// rec64 layouts
+//   disk     [0..2] n^ (unit normal)  [3] k = sum(pos*n^) - n^.eye  [4..6] oc = eye - pos  [7] r^2
+//   plane    [0..2] n^                [3] k
+//   sphere   [0..2] oc = eye - pos    [3] c = |oc|^2 - r^2
+//   triangle [0..2] n^ [3] k [4..12] v0,v1,v2 (xyz) [13..21] e01,e12,e20 [22..23] pad
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) {
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+// numpy/renderer.py:145-169 for pixel (column c, row r) of the full W x H grid.
+__device__ __forceinline__ void pixel_ray(const FrameDev& F, int c, int r, double d[3]) {
+  // np.linspace(-1, 1, W)[c], np.linspace(1, -1, H)[r]: start + i*step, last sample forced to stop
+  const double xs = (F.W > 1 && c == F.W - 1) ? 1.0 : (c * F.step_x + -1.0);
+  const double ys = (F.H > 1 && r == F.H - 1) ? -1.0 : (r * F.step_y + 1.0);
+  const double X = xs * F.half_w, Y = ys * F.half_h, Z = -F.focal;
+  double v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = (F.bx[i] * X + F.by[i] * Y) + F.bz[i] * Z;
+  const double len = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[i] = v[i] / len;
+}
+
+// ---- intersections: return the reference's ray_distance for one (ray, primitive) pair ------------
+// plane: numpy/renderer.py:53-74
+__device__ __forceinline__ double hit_plane64(const double* R, const double d[3]) {
+  return R[3] / dot3(R, d);
+}
+
+// disk: numpy/renderer.py:77-93 -- plane hit kept where |p - c|^2 <= r^2, else inf
+__device__ __forceinline__ double hit_disk64(const double* R, const double d[3]) {
+  const double t = R[3] / dot3(R, d);
+  const double qx = R[4] + t * d[0], qy = R[5] + t * d[1], qz = R[6] + t * d[2];
+  const double dist_sqr = (qx * qx + qy * qy) + qz * qz;
+  return (dist_sqr <= R[7]) ? t : __builtin_inf();
+}
+
+// sphere: numpy/renderer.py:9-50 with its sentinels (Q2): bad roots -> 1.0, missed line -> 0
+__device__ __forceinline__ double hit_sphere64(const double* R, const double d[3], bool* line_hits = nullptr) {
+  const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+  const double b = 2.0 * dot3(R, d);
+  const double disc = b * b - 4.0 * a * R[3];
+  const bool ok = disc >= 0.0;
+  if (line_hits) *line_hits = ok;
+  const double root = sqrt(ok ? disc : 0.0);
+  const double inv = 1.0 / (2.0 * a);
+  double t1 = (-b - root) * inv, t2 = (-b + root) * inv;
+  t1 = (ok && t1 >= 0.0) ? t1 : 1.0;
+  t2 = (ok && t2 >= 0.0) ? t2 : 1.0;
+  const double t = fmin(t1, t2);
+  return ok ? t : 0.0;
+}
+
+// triangle: numpy/renderer.py:96-130 -- plane through vertex 0 with the supplied normal, then
+// dot(cross(edge_i, p - v_i), n^) >= 0 for the three edges, p = eye + t*d
+__device__ __forceinline__ double hit_triangle64(const double* R, const double o[3], const double d[3]) {
+  const double t = R[3] / dot3(R, d);
+  const double p[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+  bool inside = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double* v = R + 4 + 3 * i;
+    const double* e = R + 13 + 3 * i;
+    const double w[3] = {p[0] - v[0], p[1] - v[1], p[2] - v[2]};
+    const double cx = e[1] * w[2] - e[2] * w[1];
+    const double cy = e[2] * w[0] - e[0] * w[2];
+    const double cz = e[0] * w[1] - e[1] * w[0];
+    inside = inside && (((cx * R[0] + cy * R[1]) + cz * R[2]) >= 0.0);
+  }
+  return inside ? t : __builtin_inf();
+}
+
+__device__ __forceinline__ double hit_any64(int type, const double* R, const double o[3], const double d[3]) {
+  switch (type) {
+    case SRH_PRIM_DISK: return hit_disk64(R, d);
+    case SRH_PRIM_PLANE: return hit_plane64(R, d);
+    case SRH_PRIM_SPHERE: return hit_sphere64(R, d);
+    default: return hit_triangle64(R, o, d);
+  }
+}
+
+// numpy/renderer.py:219-223: a hit is valid iff near <= t <= far; the running minimum only moves on
+// a strictly smaller t, so the lowest global index wins ties exactly like np.argmin.
+__device__ __forceinline__ void resolve(const FrameDev& F, double t, int gidx, double& best, int& besti) {
+  if (F.near_clip <= t && t <= F.far_clip && t < best) { best = t; besti = gidx; }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Fragment stage for one pixel (numpy/renderer.py:228-263): gathers the winner's normal / position /
+// albedo, Lambert over all lights with no per-light clamp (Q4, Q5), depth mask, clip, tonemap.
+// `z` is +inf and `win` 0 for an all-miss pixel, exactly what np.argmin hands the reference; the
+// garbage that produces is zeroed by the depth mask just as it is there.
+__device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3], double z, int win,
+                                            float rgb[3]) {
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+    if (i < F.nseg && win >= F.seg[i].first) s = i;
+  const SegDev& S = F.seg[s];
+  const int li = win - S.first;
+  const double p[4] = {F.o[0] + z * d[0], F.o[1] + z * d[1], F.o[2] + z * d[2], 1.0 + z * 0.0};
+
+  double n[4];
+  if (S.type == SRH_PRIM_SPHERE) {
+    // (p - c) / |p - c|, zero where the ray's line misses the sphere (:45-47)
+    const float* c = S.pos + 4 * li;
+    const double v[4] = {p[0] - (double)c[0], p[1] - (double)c[1], p[2] - (double)c[2], p[3] - (double)c[3]};
+    const double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    bool ok;
+    (void)hit_sphere64(S.rec64 + 4 * li, d, &ok);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n[i] = ok ? v[i] / len : 0.0;
+  } else {
+    // ops.normalize over all four components, zero vectors stay zero (numpy/ops.py:18-26)
+    const float* q = S.normal + 4 * li;
+    const double v[4] = {(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
+    double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    if (!(fabs(len) > 0.0)) len = 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n[i] = v[i] / len;
+  }
+  const int m = clampi(S.mat[li], 0, F.nmat - 1);
+  const double alb[3] = {(double)F.albedo[3 * m], (double)F.albedo[3 * m + 1], (double)F.albedo[3 * m + 2]};
+
+  double im[3] = {0.0, 0.0, 0.0};
+  for (int l = 0; l < F.nlights; ++l) {
+    const float* lp = F.lpos + 4 * l;
+    double v[4] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2], (double)lp[3] - p[3]};
+    double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    if (len <= 0.0) len = 1.0;                                    // Q7
+    const double ndotl = ((n[0] * (v[0] / len) + n[1] * (v[1] / len)) + n[2] * (v[2] / len)) + n[3] * (v[3] / len);
+    const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const double term = (ndotl * (double)F.colors[3 * ci + ch]) * alb[ch];
+      im[ch] = (l == 0) ? term : im[ch] + term;
+    }
+  }
+  const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    double v = masked ? 0.0 : im[ch];
+    if (v < 0.0) v = 0.0;                                         // :259, NaN stays NaN
+    if (F.tonemap) v = pow(v, F.gamma);                           // :262-263
+    rgb[ch] = (float)v;
+  }
+}
+
+}  // namespace srh

@@ -1,0 +1,314 @@
+"""The hip backend's mirror of the reference backend interface: ``render(scene, **params) -> dict``.
+
+Same call and same scene dict as ``diffrend.numpy.renderer.render`` (numpy/renderer.py:204-272) and
+``diffrend.torch.renderer.render`` (torch/renderer.py:136-355); the work is done by hand-written
+gfx950 kernels behind the C ABI of include/srh.h.  PyTorch is used for device memory and streams only.
+
+Layers
+  flatten_scene()   expanded scene dict (lists / ndarrays / tensors) -> SceneBuffers: contiguous fp32 /
+                    int32 device arrays in the reference's layouts and concatenation order, plus the
+                    ctypes descriptors libsrh consumes.  Done once per scene; stays resident in HBM.
+  render_buffers()  one frame from resident buffers and a camera (what bench.py times).
+  render()          the drop-in: flatten + render_buffers + reference-shaped result dict.
+
+There is no CPU fallback: without a GPU or without libsrh.so these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scene import PRIM_CODE, _OBJ_FIELDS
+
+# keyword arguments of the torch backend's render() that callers pass routinely (torch/renderer.py:
+# 152-168, 233-245, 291, 326-327); the hip backend accepts them so call sites need no edits.
+_TORCH_ONLY_KWARGS = {"tiled", "tile_size", "backface_culling", "norm_depth_image_only", "vis_stat",
+                      "shadow", "double_sided", "use_quartic"}
+
+
+def _require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("the hip backend needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback -- use the reference's numpy backend instead")
+
+
+def _as_tensor(x, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+def _host_view(x) -> Optional[np.ndarray]:
+    """numpy view for host-side validation; None for device tensors (not worth a sync)."""
+    if isinstance(x, torch.Tensor):
+        return None if x.is_cuda else x.detach().numpy()
+    return np.asarray(x)
+
+
+@dataclass
+class SceneBuffers:
+    """A scene resident in HBM in the layouts of include/srh.h."""
+    device: torch.device
+    kinds: List[str]
+    counts: List[int]
+    tensors: Dict[str, torch.Tensor]          # "<kind>.<field>", "lights.pos", ... (keeps memory alive)
+    objects: _lib.SrhObjects
+    lights: _lib.SrhLights
+    materials: _lib.SrhMaterials
+    gamma: Optional[float]
+    workspace: torch.Tensor
+    total: int = 0
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.tensors.values())
+
+
+def _check_w(name: str, arr: Optional[np.ndarray], want: float) -> None:
+    if arr is None or arr.size == 0:
+        return
+    w = arr[..., 3]
+    if not np.all(w == want):
+        raise ValueError(f"{name}: homogeneous w must be {want:g} for every row (the reference's convention, "
+                         f"docs/scene_description.md:3-5); found {np.unique(w)[:4]}")
+
+
+def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True) -> SceneBuffers:
+    """Upload an expanded scene.  Object batches keep scene['objects'] dict order, which defines the
+    global primitive numbering (numpy/renderer.py:172-201).  The caller's scene is not modified."""
+    device = torch.device(device)
+    _require_gpu(device)
+    lib = _lib.load()
+    objs = scene["objects"]
+    if not objs:
+        raise ValueError("scene['objects'] is empty")
+    if len(objs) > _lib.MAX_SEGMENTS:
+        raise ValueError(f"at most {_lib.MAX_SEGMENTS} object batches")
+    f32, i32 = torch.float32, torch.int32
+    tensors: Dict[str, torch.Tensor] = {}
+    kinds: List[str] = []
+    counts: List[int] = []
+    ob = _lib.SrhObjects()
+    n_mat = int(np.asarray(_shape_of(scene["materials"]["albedo"]))[0])
+    for s, (kind, grp) in enumerate(objs.items()):
+        if kind not in PRIM_CODE:
+            raise ValueError(f"unknown object type {kind!r}; expanded scenes hold disk / plane / sphere / "
+                             f"triangle (use surf_renderer_amd.scene.load_scene for JSON 'obj' lists)")
+        seg = ob.seg[s]
+        seg.type = PRIM_CODE[kind]
+        count = None
+        for name in _OBJ_FIELDS[kind]:
+            t = _as_tensor(grp[name], f32, device)
+            if name == "radius":
+                t = t.reshape(-1)
+            elif name == "face":
+                t = t.reshape(-1, 3, 4)
+            else:
+                t = t.reshape(-1, 4)
+            if count is None:
+                count = t.shape[0]
+            elif t.shape[0] != count:
+                raise ValueError(f"{kind}.{name}: {t.shape[0]} rows, expected {count}")
+            if validate:
+                host = _host_view(grp[name])
+                if name in ("pos", "face"):
+                    _check_w(f"{kind}.{name}", None if host is None else host.reshape(-1, 4), 1.0)
+                elif name == "normal":
+                    _check_w(f"{kind}.{name}", None if host is None else host.reshape(-1, 4), 0.0)
+            tensors[f"{kind}.{name}"] = t
+            setattr(seg, name, t.data_ptr())
+        mi_host = _host_view(grp["material_idx"])
+        if validate and mi_host is not None and mi_host.size:
+            if mi_host.min() < 0 or mi_host.max() >= n_mat:
+                raise IndexError(f"{kind}.material_idx out of range for {n_mat} materials")
+        mi = _as_tensor(grp["material_idx"], i32, device).reshape(-1)
+        if mi.shape[0] != count:
+            raise ValueError(f"{kind}.material_idx: {mi.shape[0]} entries, expected {count}")
+        if count == 0:
+            raise ValueError(f"{kind}: empty batch")
+        tensors[f"{kind}.material_idx"] = mi
+        seg.material_idx = mi.data_ptr()
+        seg.count = count
+        kinds.append(kind)
+        counts.append(count)
+    ob.n_segments = len(kinds)
+
+    lights = scene["lights"]
+    lpos = _as_tensor(lights["pos"], f32, device).reshape(-1, 4)
+    lidx = _as_tensor(lights["color_idx"], i32, device).reshape(-1)
+    colors = _as_tensor(scene["colors"], f32, device).reshape(-1, 3)
+    albedo = _as_tensor(scene["materials"]["albedo"], f32, device).reshape(-1, 3)
+    if lpos.shape[0] != lidx.shape[0]:
+        raise ValueError("lights.pos and lights.color_idx disagree on the number of lights")
+    if lpos.shape[0] > _lib.MAX_LIGHTS:
+        raise ValueError(f"at most {_lib.MAX_LIGHTS} lights")
+    if validate:
+        _check_w("lights.pos", _host_view(lights["pos"]), 1.0)
+        ci = _host_view(lights["color_idx"])
+        if ci is not None and ci.size and (ci.min() < 0 or ci.max() >= colors.shape[0]):
+            raise IndexError("lights.color_idx out of range for the colour table")
+    tensors.update({"lights.pos": lpos, "lights.color_idx": lidx, "colors": colors, "materials.albedo": albedo})
+    ls = _lib.SrhLights(n_lights=lpos.shape[0], n_colors=colors.shape[0], pos=lpos.data_ptr(),
+                        color_idx=lidx.data_ptr(), colors=colors.data_ptr())
+    ms = _lib.SrhMaterials(n_materials=albedo.shape[0], albedo=albedo.data_ptr())
+
+    gamma = None
+    if "tonemap" in scene:
+        tm = scene["tonemap"]
+        if tm.get("type", "gamma") != "gamma":
+            raise ValueError(f"tonemap type {tm.get('type')!r}: only 'gamma' exists (numpy/renderer.py:140-142)")
+        g = tm["gamma"]
+        gamma = float(g.detach().cpu().reshape(-1)[0]) if isinstance(g, torch.Tensor) else float(np.ravel(g)[0])
+
+    ws_bytes = lib.srh_workspace_bytes(C.byref(ob))
+    if ws_bytes == 0:
+        raise _lib.SrhError(-1, lib.srh_last_error().decode())
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    return SceneBuffers(device=device, kinds=kinds, counts=counts, tensors=tensors, objects=ob, lights=ls,
+                        materials=ms, gamma=gamma, workspace=workspace, total=sum(counts))
+
+
+def _shape_of(x):
+    if isinstance(x, torch.Tensor):
+        return tuple(x.shape)
+    return np.asarray(x).shape
+
+
+def camera_struct(camera: Dict[str, Any]) -> _lib.SrhCamera:
+    """scene['camera'] -> SrhCamera.  List-typed ``at`` / ``up`` take the reference's float32 detour
+    (numpy/ops.py:95-100, quirk Q11); arrays and tensors are taken at full precision."""
+    def vec(val, f32_if_list: bool):
+        if isinstance(val, torch.Tensor):
+            return val.detach().cpu().double().numpy().reshape(-1)
+        if f32_if_list and isinstance(val, (list, tuple)):
+            return np.asarray(val, dtype=np.float32).astype(np.float64).reshape(-1)
+        return np.asarray(val, dtype=np.float64).reshape(-1)
+
+    def scalar(val) -> float:
+        if isinstance(val, torch.Tensor):
+            return float(val.detach().cpu().reshape(-1)[0])
+        return float(np.ravel(val)[0])
+
+    cam = _lib.SrhCamera()
+    eye, at, up = vec(camera["eye"], False), vec(camera["at"], True), vec(camera["up"], True)
+    if up.size == 3:
+        up = np.append(up, 0.0)
+    if eye.size != 4 or at.size != 4 or up.size != 4:
+        raise ValueError("camera.eye / camera.at must be homogeneous 4-vectors, camera.up a 3- or 4-vector")
+    cam.eye[:] = eye.tolist()
+    cam.at[:] = at.tolist()
+    cam.up[:] = up.tolist()
+    cam.fovy = scalar(camera["fovy"])
+    cam.focal_length = scalar(camera["focal_length"])
+    cam.near_clip = scalar(camera["near"])
+    cam.far_clip = scalar(camera["far"])
+    vp = [int(v) for v in np.ravel(_host_view(camera["viewport"]) if not isinstance(camera["viewport"], torch.Tensor)
+                                   else camera["viewport"].cpu().numpy())]
+    cam.viewport[:] = vp
+    if str(camera.get("proj_type", "perspective")) != "perspective":
+        raise NotImplementedError("the numpy backend, which this backend matches, is perspective-only")
+    return cam
+
+
+def frame_size(cam: _lib.SrhCamera) -> Tuple[int, int]:
+    return cam.viewport[2] - cam.viewport[0], cam.viewport[3] - cam.viewport[1]
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
+                   mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
+                   want_nearest: bool = True):
+    """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
+    enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
+    preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None)."""
+    lib = _lib.load()
+    width, height = frame_size(cam)
+    r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
+    h = r1 - r0
+    if out is None:
+        image = torch.empty((max(h, 0), width, 3), dtype=torch.float32, device=buf.device)
+        depth = torch.empty((max(h, 0), width), dtype=torch.float32, device=buf.device)
+        nearest = torch.empty((max(h, 0), width), dtype=torch.int32, device=buf.device) if want_nearest else None
+    else:
+        image, depth, nearest = out
+        for t, shape, dt in ((image, (h, width, 3), torch.float32), (depth, (h, width), torch.float32),
+                             (nearest, (h, width), torch.int32)):
+            if t is None:
+                continue
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != buf.device:
+                raise ValueError(f"out buffer mismatch: want contiguous {dt} {shape} on {buf.device}, "
+                                 f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[mode],
+                            tonemap_gamma=0 if buf.gamma is None else 1,
+                            gamma=1.0 if buf.gamma is None else buf.gamma)
+    with torch.cuda.device(buf.device):
+        rc = lib.srh_render_fwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                C.byref(params), buf.workspace.data_ptr(), buf.workspace.numel(),
+                                image.data_ptr(), depth.data_ptr(),
+                                nearest.data_ptr() if nearest is not None else None, _stream_ptr(buf.device))
+    _lib.check(rc)
+    return image, depth, nearest
+
+
+def generate_rays(camera: Dict[str, Any], device="cuda", rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """``ray_dir`` as the reference returns it: (4, N) unit directions, row-major over the image
+    (numpy/renderer.py:145-169)."""
+    device = torch.device(device)
+    _require_gpu(device)
+    lib = _lib.load()
+    cam = camera_struct(camera)
+    width, height = frame_size(cam)
+    r0, r1 = (0, height) if rows is None else rows
+    out = torch.empty((4, max(r1 - r0, 0) * width), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.srh_generate_rays(C.byref(cam), r0, r1, out.data_ptr(), _stream_ptr(device)))
+    return out
+
+
+class RenderResult(dict):
+    """The reference's result dict.  ``image`` (H,W,3), ``depth`` (H,W) and ``nearest`` (H,W) are always
+    present; ``ray_dir`` (4,N) is produced on first access.  The three O(M*N) entries of the numpy
+    backend (``ray_dist``, ``obj_dist``, ``valid_pixels``) do not exist in a streaming renderer."""
+
+    def __init__(self, camera, device, *args, **kw):
+        super().__init__(*args, **kw)
+        self._camera, self._device = camera, device
+
+    def __missing__(self, key):
+        if key == "ray_dir":
+            val = generate_rays(self._camera, self._device)
+            self[key] = val
+            return val
+        if key in ("ray_dist", "obj_dist", "valid_pixels"):
+            raise KeyError(f"{key!r}: the hip backend never materialises (primitives x pixels) arrays")
+        raise KeyError(key)
+
+
+def render(scene: Dict[str, Any], **params) -> RenderResult:
+    """Drop-in for the reference backends' ``render(scene)``.
+
+    Returns torch tensors on the render device: ``image`` (H,W,3) float32, ``depth`` (H,W) float32 with
+    +inf where nothing is hit, ``nearest`` (H,W) int64 (0 where nothing is hit), matching
+    ``diffrend.numpy.renderer.render`` within fp32 rounding of the stored outputs.
+
+    Keyword arguments: ``device`` ('cuda'), ``mode`` ('auto' | 'exact' | 'fast'), ``rows`` ((r0, r1) slab),
+    ``validate`` (host-side index / w checks).  The torch backend's kwargs (tiled, tile_size, shadow, ...)
+    are accepted and ignored: the numpy backend this one matches has none of those features.
+    """
+    unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate"}
+    if unknown:
+        raise TypeError(f"render() got unexpected keyword arguments {sorted(unknown)}")
+    device = torch.device(params.get("device", "cuda"))
+    buf = flatten_scene(scene, device, validate=params.get("validate", True))
+    cam = camera_struct(scene["camera"])
+    image, depth, nearest = render_buffers(buf, cam, rows=params.get("rows"), mode=params.get("mode", "auto"))
+    return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64))
