@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward render of the synthetic 100 000-disc scene at 2048 x 2048 (BASELINE.json
+configs[4]), framebuffer row-tiled over N MI355X with one RCCL gather per frame.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one frame: every rank renders its row slab from primitive arrays already resident in HBM
+(prep kernel + render kernel), then the slabs are gathered on rank 0.  Rank 0 prints ONE JSON line.
+``value`` = frames/s of the whole job; tests/s = primitives x pixels x frames/s (algorithmic pairs, i.e.
+what the reference evaluates, whatever the kernel skips).  Total work is fixed as N grows -> "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_F32_PEAK_TFLOPS = 157.3   # fp32 vector peak
+FLOP_PER_DISK_TEST = 17        # SURVEY.md section 8d (arithmetic only, per-primitive constants hoisted)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="auto", choices=["auto", "exact", "fast"])
+    ap.add_argument("--prims", type=int, default=100_000)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pixels", type=int, default=384, help="pixels in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, prims, width, height, npix):
+    """The oracle (numpy restatement of the reference's CPU path) timed on this host, on a bounded
+    sample of the same workload: `npix` consecutive pixels from the middle image row against all
+    primitives.  numpy's elementwise kernels run on one core."""
+    from oracle import np_oracle                       # checker / baseline only -- never the product path
+    from surf_renderer_amd.scene import scene_to_numpy
+    sc = scene_to_numpy(scene, round_fp32=True)
+    p0 = (height // 2) * width + (width - npix) // 2
+    t0 = time.perf_counter()
+    np_oracle.render(sc, tile=64, window=(p0, p0 + npix))
+    dt = time.perf_counter() - t0
+    tests = float(prims) * npix
+    tps = tests / dt
+    return {"value": tps / (float(prims) * width * height), "unit": "frames/s", "cores": 1,
+            "kind": "port", "mtests_per_s": tps / 1e6,
+            "extrapolated_s_per_frame": float(prims) * width * height / tps,
+            "host_cpus": os.cpu_count(),
+            "sample": f"{npix} consecutive pixels of the middle row x {prims} discs ({tests:.3g} tests, "
+                      f"{dt:.1f} s), oracle/np_oracle.py fp64, pixel tile 64; frames/s extrapolated"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from surf_renderer_amd import _lib, renderer, synthetic
+    from surf_renderer_amd.dist import gather_rows, row_slab
+
+    W, H, M = args.width, args.height, args.prims
+    scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
+    buf = renderer.flatten_scene(scene, device)
+    cam = renderer.camera_struct(scene["camera"])
+    r0, r1 = row_slab(H, rank, world)
+    h = r1 - r0
+
+    # one (rows, 4W) fp32 slab per rank: [W x rgb | W x depth] per row, so a single gather moves both
+    if rank == 0:
+        frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
+        slab = frame[r0:r1]
+    else:
+        frame = None
+        slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
+    image = slab.as_strided((h, W, 3), (4 * W, 3, 1), slab.storage_offset())
+    depth = slab.as_strided((h, W), (4 * W, 1), slab.storage_offset() + 3 * W)
+    events = [_lib.EventPair() for _ in range(args.steps)]
+
+    def step(ev=None):
+        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None), events=ev)
+        if world > 1:
+            gather_rows(slab, frame, H, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([e.elapsed_ms() for e in events]))
+    for e in events:
+        e.close()
+
+    if rank == 0:
+        fps = args.steps / elapsed
+        tests = float(M) * W * H
+        # algorithmic HBM bytes of one render launch on this rank: primitives read once in the
+        # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
+        alg_bytes = M * 40.0 + h * W * (12.0 + 4.0)
+        ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        rank_tests = float(M) * W * h
+        valu_tflops = rank_tests * FLOP_PER_DISK_TEST / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
+            "value": fps, "unit": "frames/s", "gtests_per_s": fps * tests / 1e9,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if args.mode == "exact" else "f32 reject + f64 confirm",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: 100k synthetic disk splats, 2048x2048, forward render, "
+                                   "framebuffer row-tiled across ranks + 1 gather",
+                       "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
+                       "parallelism": f"rows/{world}"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": alg_bytes,
+                         "note": "the path is VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
+            "valu": {"achieved": valu_tflops, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": valu_tflops / VALU_F32_PEAK_TFLOPS,
+                     "flop_per_test": FLOP_PER_DISK_TEST, "tests_per_launch": rank_tests},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

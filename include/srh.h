@@ -104,6 +104,11 @@ typedef struct SrhParams {
   int32_t mode;                 /* SRH_MODE_* */
   int32_t tonemap_gamma;        /* 1: image <- image ** gamma  (scene has a 'tonemap' entry, :262) */
   double gamma;
+  int64_t image_row_stride;     /* elements between consecutive output rows; 0 = dense (3*W, W, W). */
+  int64_t depth_row_stride;     /* Lets image and depth rows interleave in one (rows, 4*W) slab so that a */
+  int64_t nearest_row_stride;   /* multi-GPU frame is collected by a single gather. */
+  void* ev_start;               /* optional hipEvent_t pair recorded on `stream` immediately before and */
+  void* ev_stop;                /* after the frame's dominant kernel (measurement hook); NULL = off */
 } SrhParams;
 
 int srh_abi_version(void);
@@ -126,6 +131,12 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                    const SrhMaterials* materials, const SrhParams* params,
                    void* workspace, size_t workspace_bytes,
                    float* image, float* depth, int32_t* nearest, void* stream);
+
+/* measurement helpers: timing-enabled HIP events usable as SrhParams.ev_start / ev_stop.
+ * srh_event_elapsed_ms waits for `stop` to complete (the only call here that blocks the host). */
+int srh_event_create(void** event);
+int srh_event_destroy(void* event);
+int srh_event_elapsed_ms(void* start, void* stop, float* ms);
 
 #ifdef __cplusplus
 }

@@ -180,15 +180,16 @@ def _winner_normals(segs, nearest, p_win, eye, d, dtype):
     return out
 
 
-def render(scene, tile=2048, dtype=np.float64, rows=None):
+def render(scene, tile=2048, dtype=np.float64, rows=None, window=None):
     """Restatement of numpy/renderer.py:204-272 for the ndarray-leaf scene dict the reference
     consumes.  ``rows=(r0, r1)`` renders only image rows [r0, r1) of the full camera (outputs then
-    have r1 - r0 rows); ``dtype=np.float32`` is a diagnostic mode that repeats the same formulas in
+    have r1 - r0 rows); ``window=(p0, p1)`` renders only the flat pixel range [p0, p1) of the row-major image
+    (outputs then come back flat, used for bounded CPU timing samples); ``dtype=np.float32`` is a diagnostic mode that repeats the same formulas in
     single precision.  Returns image (h,W,3), depth (h,W), nearest (h,W) int64, ray_dir (4,n)."""
     cam = scene['camera']
     eye, ray_dir, H, W = generate_rays(cam, dtype)
     r0, r1 = (0, H) if rows is None else rows
-    ray_dir = ray_dir[:, r0 * W:r1 * W]
+    ray_dir = ray_dir[:, r0 * W:r1 * W] if window is None else ray_dir[:, window[0]:window[1]]
     npix = ray_dir.shape[1]
     near, far = cam['near'], cam['far']
 
@@ -254,6 +255,8 @@ def render(scene, tile=2048, dtype=np.float64, rows=None):
             if tm['type'] == 'gamma':
                 image = image ** np.asarray(tm['gamma']).astype(dtype).ravel()[0]
 
+    if window is not None:
+        return {'image': image, 'depth': depth, 'nearest': nearest, 'ray_dir': ray_dir}
     h = r1 - r0
     return {'image': image.reshape(h, W, 3), 'depth': depth.reshape(h, W),
             'nearest': nearest.reshape(h, W), 'ray_dir': ray_dir}

@@ -47,10 +47,14 @@ class SrhMaterials(C.Structure):
 
 class SrhParams(C.Structure):
     _fields_ = [("row0", C.c_int32), ("row1", C.c_int32), ("mode", C.c_int32),
-                ("tonemap_gamma", C.c_int32), ("gamma", C.c_double)]
+                ("tonemap_gamma", C.c_int32), ("gamma", C.c_double),
+                ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
+                ("nearest_row_stride", C.c_int64),
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
-EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd")
+EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
+           "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
 
@@ -91,6 +95,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_render_fwd.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                    C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srh_event_create.restype = C.c_int
+    lib.srh_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.srh_event_destroy.restype = C.c_int
+    lib.srh_event_destroy.argtypes = [C.c_void_p]
+    lib.srh_event_elapsed_ms.restype = C.c_int
+    lib.srh_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     got = lib.srh_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"{path}: ABI version {got}, this package expects {ABI_VERSION}; rebuild it")
@@ -101,3 +111,25 @@ def load(build_if_missing: bool = True) -> C.CDLL:
 def check(code: int) -> None:
     if code != 0:
         raise SrhError(code, load().srh_last_error().decode("utf-8", "replace"))
+
+
+class EventPair:
+    """Two timing-enabled HIP events recorded by libsrh around a frame's dominant kernel."""
+
+    def __init__(self):
+        lib = load()
+        self.start, self.stop = C.c_void_p(), C.c_void_p()
+        check(lib.srh_event_create(C.byref(self.start)))
+        check(lib.srh_event_create(C.byref(self.stop)))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        check(load().srh_event_elapsed_ms(self.start, self.stop, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self) -> None:
+        lib = load()
+        for ev in (self.start, self.stop):
+            if ev:
+                lib.srh_event_destroy(ev)
+        self.start = self.stop = C.c_void_p()

@@ -116,12 +116,13 @@ __global__ __launch_bounds__(256) void k_rays(FrameDev F, float* ray_dir) {
 __device__ __forceinline__ void store_pixel(const FrameDev& F, int c, int r, const float rgb[3], double z, int win,
                                             float* __restrict__ image, float* __restrict__ depth,
                                             int32_t* __restrict__ nearest) {
-  const size_t p = (size_t)(r - F.row0) * F.W + c;
-  image[3 * p + 0] = rgb[0];
-  image[3 * p + 1] = rgb[1];
-  image[3 * p + 2] = rgb[2];
-  depth[p] = (float)z;
-  if (nearest) nearest[p] = win;
+  const size_t row = (size_t)(r - F.row0);
+  float* px = image + row * F.img_stride + 3 * (size_t)c;
+  px[0] = rgb[0];
+  px[1] = rgb[1];
+  px[2] = rgb[2];
+  depth[row * F.depth_stride + c] = (float)z;
+  if (nearest) nearest[row * F.near_stride + c] = win;
 }
 
 __global__ __launch_bounds__(256) void k_render_exact(FrameDev F, float* __restrict__ image,
@@ -285,6 +286,11 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   F.row1 = params->row1;
   F.gamma = params->gamma;
   F.tonemap = params->tonemap_gamma ? 1 : 0;
+  F.img_stride = params->image_row_stride ? params->image_row_stride : 3 * (int64_t)F.W;
+  F.depth_stride = params->depth_row_stride ? params->depth_row_stride : (int64_t)F.W;
+  F.near_stride = params->nearest_row_stride ? params->nearest_row_stride : (int64_t)F.W;
+  if (F.img_stride < 3 * (int64_t)F.W || F.depth_stride < F.W || F.near_stride < F.W)
+    return fail(SRH_E_RANGE, "output row strides shorter than a row");
   F.nseg = objects->n_segments;
   F.nlights = lights->n_lights;
   F.ncolors = lights->n_colors;
@@ -318,9 +324,34 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                        (double*)S.rec64);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+  if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
   hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
+  if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "render launch");
+}
+
+int srh_event_create(void** event) {
+  if (!event) return fail(SRH_E_NULL, "event is NULL");
+  hipEvent_t ev;
+  hipError_t e = hipEventCreate(&ev);
+  if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+  *event = (void*)ev;
+  return SRH_OK;
+}
+
+int srh_event_destroy(void* event) {
+  if (!event) return SRH_OK;
+  hipError_t e = hipEventDestroy((hipEvent_t)event);
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "hipEventDestroy");
+}
+
+int srh_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return fail(SRH_E_NULL, "event / ms is NULL");
+  hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+  if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+  e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "hipEventElapsedTime");
 }
 
 }  // extern "C"

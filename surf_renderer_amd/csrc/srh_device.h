@@ -38,6 +38,7 @@ struct FrameDev {
   double near_clip, far_clip, gamma;
   int32_t W, H, row0, row1;
   int32_t nseg, total, nlights, ncolors, nmat, tonemap;
+  int64_t img_stride, depth_stride, near_stride;   // elements per output row
   SegDev seg[SRH_MAX_SEGMENTS];
   const float* lpos;
   const int32_t* lcidx;

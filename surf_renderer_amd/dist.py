@@ -1,0 +1,62 @@
+"""Multi-GPU framing: the framebuffer is tiled by rows across ranks, one process per GPU.
+
+Pixels are independent (reference README.md:81-84, docs/renderer.md:34-35), so rank g of P renders the
+contiguous row slab ``row_slab(H, g, P)`` with a full replica of the (small) primitive arrays and the
+slabs are collected on one rank by a single gather per frame -- RCCL over xGMI when the process group
+is "nccl", gloo in the CPU tests.  Nothing is reduced, so there is no ring all-reduce on the path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def row_slab(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [r0, r1) owned by ``rank``: contiguous, in rank order, sizes differing by at most one
+    (the first ``height % world`` ranks take the extra row).  Slabs may be empty when world > height."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} of {world}")
+    base, extra = divmod(height, world)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def all_slabs(height: int, world: int) -> List[Tuple[int, int]]:
+    return [row_slab(height, g, world) for g in range(world)]
+
+
+def gather_rows(slab: torch.Tensor, full: Optional[torch.Tensor], height: int, dst: int = 0,
+                group: Optional[dist.ProcessGroup] = None) -> None:
+    """Collect per-rank row slabs ``slab`` ((h_g, W, ...) contiguous) into ``full`` ((H, W, ...), only
+    needed on ``dst``).  Equal slabs use one ``gather`` whose receive list are views of ``full`` (no
+    staging copy); ragged slabs fall back to one batched send/recv group."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    slabs = all_slabs(height, world)
+    if world == 1:
+        if full is not None and full.data_ptr() != slab.data_ptr():
+            full.copy_(slab)
+        return
+    equal = len({r1 - r0 for r0, r1 in slabs}) == 1
+    if rank == dst:
+        if full is None or full.shape[0] != height:
+            raise ValueError("the destination rank must pass the full (H, W, ...) buffer")
+        views = [full[r0:r1] for r0, r1 in slabs]
+    if equal:
+        dist.gather(slab, gather_list=views if rank == dst else None, dst=dst, group=group)
+        return
+    ops = []
+    if rank == dst:
+        r0, r1 = slabs[dst]
+        if full[r0:r1].data_ptr() != slab.data_ptr():
+            full[r0:r1].copy_(slab)
+        for g, (a, b) in enumerate(slabs):
+            if g != dst and b > a:
+                ops.append(dist.P2POp(dist.irecv, views[g], g, group))
+    elif slab.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, slab, dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()

@@ -226,7 +226,7 @@ def _stream_ptr(device: torch.device) -> int:
 
 def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                    mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
-                   want_nearest: bool = True):
+                   want_nearest: bool = True, events: Optional[_lib.EventPair] = None):
     """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
     enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
     preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None)."""
@@ -244,12 +244,17 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                              (nearest, (h, width), torch.int32)):
             if t is None:
                 continue
-            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != buf.device:
-                raise ValueError(f"out buffer mismatch: want contiguous {dt} {shape} on {buf.device}, "
-                                 f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+            inner = tuple(t.stride()[1:]) == ((3, 1) if len(shape) == 3 else (1,))
+            if tuple(t.shape) != shape or t.dtype != dt or not inner or t.device != buf.device:
+                raise ValueError(f"out buffer mismatch: want {dt} {shape} with dense rows on {buf.device}, "
+                                 f"got {t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
     params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[mode],
                             tonemap_gamma=0 if buf.gamma is None else 1,
-                            gamma=1.0 if buf.gamma is None else buf.gamma)
+                            gamma=1.0 if buf.gamma is None else buf.gamma,
+                            image_row_stride=image.stride(0) if h > 1 else 0,
+                            depth_row_stride=depth.stride(0) if h > 1 else 0,
+                            nearest_row_stride=nearest.stride(0) if (nearest is not None and h > 1) else 0,
+                            ev_start=events.start if events else None, ev_stop=events.stop if events else None)
     with torch.cuda.device(buf.device):
         rc = lib.srh_render_fwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                 C.byref(params), buf.workspace.data_ptr(), buf.workspace.numel(),
