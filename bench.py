@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="auto", choices=["auto", "exact", "fast"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "exact", "fast", "binned"])
     ap.add_argument("--prims", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)

@@ -51,7 +51,8 @@ enum {
 enum {
   SRH_MODE_AUTO = 0,      /* the fastest exact path */
   SRH_MODE_EXACT = 1,     /* every (pixel, primitive) pair through the fp64 intersection (checker mode) */
-  SRH_MODE_FAST = 2       /* fp32 conservative reject per pair + fp64 confirmation of the survivors */
+  SRH_MODE_FAST = 2,      /* all pairs: fp32 conservative screen-space reject + fp64 confirmation of survivors */
+  SRH_MODE_BINNED = 3     /* primitives binned to 16x16-pixel tiles by their screen bounding box, then as FAST */
 };
 
 /* scene['camera'] (numpy/renderer.py:145-169, numpy/ops.py:88-115).  Host memory, float64.
@@ -114,9 +115,10 @@ typedef struct SrhParams {
 int srh_abi_version(void);
 const char* srh_last_error(void);
 
-/* bytes of caller-provided device scratch needed for `objects` (per-frame primitive records).
- * Returns 0 and sets srh_last_error on invalid input.  The buffer must be 256-byte aligned. */
-size_t srh_workspace_bytes(const SrhObjects* objects);
+/* bytes of caller-provided device scratch needed to render `objects` at up to width x height pixels
+ * (per-frame primitive records and tile bins).  Returns 0 and sets srh_last_error on invalid input.
+ * The buffer must be 256-byte aligned. */
+size_t srh_workspace_bytes(const SrhObjects* objects, int32_t width, int32_t height);
 
 /* replaces generate_rays (numpy/renderer.py:145-169): unit ray directions for rows [row0,row1),
  * written as the reference returns them, ray_dir (4, n) row-major with n = (row1-row0)*W. */

@@ -12,8 +12,8 @@ ABI_VERSION = 1
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
-MODE_AUTO, MODE_EXACT, MODE_FAST = 0, 1, 2
-MODES = {"auto": MODE_AUTO, "exact": MODE_EXACT, "fast": MODE_FAST}
+MODE_AUTO, MODE_EXACT, MODE_FAST, MODE_BINNED = 0, 1, 2, 3
+MODES = {"auto": MODE_AUTO, "exact": MODE_EXACT, "fast": MODE_FAST, "binned": MODE_BINNED}
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -88,7 +88,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_abi_version.restype = C.c_int
     lib.srh_last_error.restype = C.c_char_p
     lib.srh_workspace_bytes.restype = C.c_size_t
-    lib.srh_workspace_bytes.argtypes = [C.POINTER(SrhObjects)]
+    lib.srh_workspace_bytes.argtypes = [C.POINTER(SrhObjects), C.c_int32, C.c_int32]
     lib.srh_generate_rays.restype = C.c_int
     lib.srh_generate_rays.argtypes = [C.POINTER(SrhCamera), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.srh_render_fwd.restype = C.c_int

@@ -15,6 +15,8 @@
 
 #include "srh.h"
 #include "srh_device.h"
+#include "srh_reject.h"
+#include "srh_binned.h"
 
 using namespace srh;
 
@@ -38,16 +40,31 @@ int hip_fail(hipError_t e, const char* what) {
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
-constexpr int kRec32Stride[4] = {8, 4, 8, 12};  // floats per primitive reject record (FAST mode)
-
 // ------------------------------------------------------------------------------------------------
 // k_prep: per-frame primitive records
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(SegDev S, double ox, double oy, double oz, double* rec64) {
+__device__ void prep_record64(const SegDev& S, int i, const double o[3], double* R);
+
+__global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
+  const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
-  const double o[3] = {ox, oy, oz};
   double* R = rec64 + (size_t)i * kRec64Stride[S.type];
+  prep_record64(S, i, F.o, R);
+  // screen-space reject record of the FAST / binned modes, from the fp64 record just written
+  float* Q = rec32 + (size_t)i * kRec32Stride[S.type];
+  const PixelBasis B = pixel_basis(F);
+  const bool near_pos = F.near_clip > 0.0;
+  switch (S.type) {
+    case SRH_PRIM_DISK: disk_reject_record(R, B, F.W, F.H, Q); break;
+    case SRH_PRIM_SPHERE: sphere_reject_record(R, B, F.W, F.H, near_pos, Q); break;
+    case SRH_PRIM_TRIANGLE: triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q); break;
+    default: rec_always(Q, kRec32Stride[SRH_PRIM_PLANE]); break;
+  }
+  if (F.tilerange) bin_primitive(F, S.type, Q, S.first + i);
+}
+
+__device__ void prep_record64(const SegDev& S, int i, const double o[3], double* R) {
 
   double nh[3] = {0, 0, 0};
   if (S.type != SRH_PRIM_SPHERE) {
@@ -149,11 +166,118 @@ __global__ __launch_bounds__(256) void k_render_exact(FrameDev F, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_render_fast<P>: fp32 screen-space reject per pair, fp64 confirmation of the survivors.
+// A wave owns 64*P consecutive pixels of one row: lane l holds columns c0 + l + 64*j, j < P.  Reject
+// records are wave-uniform reads (scalar loads); the survivor branch is entered by a wave only when one
+// of its 64*P pixels passes the reject test, which for small primitives is a fraction of a percent of
+// the primitives, so the loop is bound by ~3 VALU operations per pair.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void confirm(const FrameDev& F, const SegDev& S, int i, int r, int cbase,
+                                        const float (&q)[P], bool ge_zero, double (&best)[P], int (&besti)[P]) {
+  const double* R = S.rec64 + (size_t)i * kRec64Stride[S.type];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const bool cand = ge_zero ? (q[j] >= 0.0f) : (q[j] <= 0.0f);
+    const int c = cbase + 64 * j;
+    if (cand && c < F.W) {
+      double d[3];
+      pixel_ray(F, c, r, d);
+      resolve(F, hit_any64(S.type, R, F.o, d), S.first + i, best[j], besti[j]);
+    }
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_render_fast(FrameDev F, float* __restrict__ image,
+                                                      float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  const int cbase = blockIdx.x * (64 * P) + threadIdx.x;
+  const int r_raw = F.row0 + blockIdx.y * 4 + threadIdx.y;
+  const bool row_live = r_raw < F.row1;
+  const int r = row_live ? r_raw : F.row1 - 1;
+  const float rf = (float)r;
+  float cf[P];
+  double best[P];
+  int besti[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    cf[j] = (float)(cbase + 64 * j);
+    best[j] = __builtin_inf();
+    besti[j] = 0;
+  }
+
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+    if (S.type == SRH_PRIM_DISK || S.type == SRH_PRIM_SPHERE) {
+      for (int i = 0; i < S.count; ++i) {
+        const float* Q = S.rec32 + (size_t)i * 8;
+        const float dr = rf - Q[1];
+        const float e = Q[3] * dr;
+        const float g = __builtin_fmaf(Q[4] * dr, dr, -1.0f);
+        float q[P];
+        float m = __builtin_inff();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const float dc = cf[j] - Q[0];
+          q[j] = __builtin_fmaf(dc, __builtin_fmaf(Q[2], dc, e), g);
+          m = fminf(m, q[j]);
+        }
+        if (m <= 0.0f) confirm<P>(F, S, i, r, cbase, q, false, best, besti);
+      }
+    } else if (S.type == SRH_PRIM_TRIANGLE) {
+      for (int i = 0; i < S.count; ++i) {
+        const float* Q = S.rec32 + (size_t)i * 12;
+        const float r0 = __builtin_fmaf(Q[1], rf, Q[2]);
+        const float r1 = __builtin_fmaf(Q[5], rf, Q[6]);
+        const float r2 = __builtin_fmaf(Q[9], rf, Q[10]);
+        float q[P];
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const float e0 = __builtin_fmaf(Q[0], cf[j], r0);
+          const float e1 = __builtin_fmaf(Q[4], cf[j], r1);
+          const float e2 = __builtin_fmaf(Q[8], cf[j], r2);
+          q[j] = fminf(fminf(e0, e1), e2);
+          m = fmaxf(m, q[j]);
+        }
+        if (m >= 0.0f) confirm<P>(F, S, i, r, cbase, q, true, best, besti);
+      }
+    } else {
+      float q[P];
+#pragma unroll
+      for (int j = 0; j < P; ++j) q[j] = 0.0f;
+      for (int i = 0; i < S.count; ++i) confirm<P>(F, S, i, r, cbase, q, false, best, besti);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int c = cbase + 64 * j;
+    if (c < F.W) {      // wave-divergent only in the last column block
+      double d[3];
+      pixel_ray(F, c, r, d);
+      float rgb[3];
+      shade_pixel(F, d, best[j], besti[j], rgb);
+      if (row_live) store_pixel(F, c, r_raw, rgb, best[j], besti[j], image, depth, nearest);
+    }
+  }
+}
+
+template <int P>
+void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, int32_t* nearest) {
+  const dim3 block(64, 4), grid((F.W + 64 * P - 1) / (64 * P), (F.row1 - F.row0 + 3) / 4);
+  hipLaunchKernelGGL(k_render_fast<P>, grid, block, 0, st, F, image, depth, nearest);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
+  size_t tilerange, counters, tile_off, large, entries;
+  size_t counters_bytes;
+  int tiles_x, tiles_y_max;
   size_t total;
 };
 
@@ -179,16 +303,33 @@ int check_objects(const SrhObjects* ob) {
   return SRH_OK;
 }
 
-WsLayout layout_for(const SrhObjects* ob) {
+// The layout depends on the primitive counts and on the full frame size only (never on the row slab), so
+// one workspace serves every slab of a frame.
+WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   WsLayout L;
-  size_t off = 0;
+  size_t off = 0, total = 0;
   for (int s = 0; s < ob->n_segments; ++s) {
     const SrhSegment& g = ob->seg[s];
     L.off64[s] = off;
     off = align_up(off + (size_t)g.count * kRec64Stride[g.type] * sizeof(double));
     L.off32[s] = off;
     off = align_up(off + (size_t)g.count * kRec32Stride[g.type] * sizeof(float));
+    total += (size_t)g.count;
   }
+  L.tiles_x = (width + kTile - 1) / kTile;
+  L.tiles_y_max = (height + kTile - 1) / kTile;
+  const size_t ntiles = (size_t)L.tiles_x * L.tiles_y_max;
+  L.tilerange = off;
+  off = align_up(off + total * 4 * sizeof(uint16_t));
+  L.counters = off;
+  L.counters_bytes = (kCounterPad + 2 * ntiles) * sizeof(uint32_t);
+  off = align_up(off + L.counters_bytes);
+  L.tile_off = off;
+  off = align_up(off + (ntiles + 1) * sizeof(uint32_t));
+  L.large = off;
+  off = align_up(off + total * sizeof(uint32_t));
+  L.entries = off;
+  off = align_up(off + total * kMaxTilesPerPrim * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -240,9 +381,14 @@ int srh_abi_version(void) { return SRH_ABI_VERSION; }
 
 const char* srh_last_error(void) { return g_err; }
 
-size_t srh_workspace_bytes(const SrhObjects* objects) {
+size_t srh_workspace_bytes(const SrhObjects* objects, int32_t width, int32_t height) {
   if (check_objects(objects) != SRH_OK) return 0;
-  return layout_for(objects).total;
+  if (width < 1 || height < 1 || (int64_t)((width + kTile - 1) / kTile) * ((height + kTile - 1) / kTile) > 65535LL * 65535LL ||
+      (width + kTile - 1) / kTile > 65535 || (height + kTile - 1) / kTile > 65535) {
+    fail(SRH_E_RANGE, "frame size %d x %d out of range", width, height);
+    return 0;
+  }
+  return layout_for(objects, width, height).total;
 }
 
 int srh_generate_rays(const SrhCamera* camera, int32_t row0, int32_t row1, float* ray_dir, void* stream) {
@@ -276,8 +422,9 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (lights->n_lights > 0 && (!lights->pos || !lights->color_idx || !lights->colors || lights->n_colors < 1))
     return fail(SRH_E_NULL, "lights arrays missing");
   if (materials->n_materials < 1 || !materials->albedo) return fail(SRH_E_NULL, "materials.albedo missing");
-  if (params->mode < SRH_MODE_AUTO || params->mode > SRH_MODE_FAST) return fail(SRH_E_TYPE, "unknown mode %d", params->mode);
-  const WsLayout L = layout_for(objects);
+  if (params->mode < SRH_MODE_AUTO || params->mode > SRH_MODE_BINNED) return fail(SRH_E_TYPE, "unknown mode %d", params->mode);
+  const int mode = params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode;
+  const WsLayout L = layout_for(objects, F.W, F.H);
   if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % kAlign) != 0)
     return fail(SRH_E_WORKSPACE, "workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", L.total,
                 workspace_bytes, workspace);
@@ -316,16 +463,43 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     first += g.count;
   }
   F.total = first;
-
   hipStream_t st = (hipStream_t)stream;
+  if (mode == SRH_MODE_BINNED) {
+    F.tiles_x = L.tiles_x;
+    F.tiles_y = (F.row1 - F.row0 + kTile - 1) / kTile;
+    F.ntiles = F.tiles_x * F.tiles_y;
+    char* ws = (char*)workspace;
+    F.tilerange = (uint16_t*)(ws + L.tilerange);
+    F.counters = (uint32_t*)(ws + L.counters);
+    F.tile_off = (uint32_t*)(ws + L.tile_off);
+    F.large = (uint32_t*)(ws + L.large);
+    F.entries = (uint32_t*)(ws + L.entries);
+    hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.ntiles) * sizeof(uint32_t), st);
+    if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
+  }
+
   for (int s = 0; s < F.nseg; ++s) {
     const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, S, F.o[0], F.o[1], F.o[2],
-                       (double*)S.rec64);
+    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64,
+                       (float*)S.rec32);
   }
-  const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+  if (mode == SRH_MODE_BINNED) {
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
+    hipLaunchKernelGGL(k_bin_fill, dim3((F.total + 255) / 256), dim3(256), 0, st, F);
+  }
   if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
-  hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
+  if (mode == SRH_MODE_BINNED) {
+    hipLaunchKernelGGL(k_render_binned, dim3(F.tiles_x, F.tiles_y), dim3(256), 0, st, F, image, depth, nearest);
+  } else if (mode == SRH_MODE_EXACT) {
+    const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+    hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
+  } else if (F.W >= 2048) {
+    launch_fast<8>(F, st, image, depth, nearest);
+  } else if (F.W >= 512) {
+    launch_fast<4>(F, st, image, depth, nearest);
+  } else {
+    launch_fast<1>(F, st, image, depth, nearest);
+  }
   if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "render launch");

@@ -16,6 +16,9 @@
 namespace srh {
 
 constexpr int kRec64Stride[4] = {8, 4, 4, 24};   // doubles per primitive record, by SRH_PRIM_*
+constexpr int kTile = 16;                         // binning tile edge in pixels
+constexpr int kMaxTilesPerPrim = 64;              // primitives overlapping more tiles go to the `large` list
+constexpr int kCounterPad = 64;                   // dwords in front of the per-tile counters
 
 // One scene['objects'] entry as the kernels see it.
 struct SegDev {
@@ -39,6 +42,13 @@ struct FrameDev {
   int32_t W, H, row0, row1;
   int32_t nseg, total, nlights, ncolors, nmat, tonemap;
   int64_t img_stride, depth_stride, near_stride;   // elements per output row
+  // tile binning (BINNED mode): 16x16-pixel tiles over the rendered row slab
+  int32_t tiles_x, tiles_y, ntiles, pad0;
+  uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
+  uint32_t* counters;                // [0] n_large | [64, 64+ntiles) tile_count | [64+ntiles, 64+2 ntiles) cursor
+  uint32_t* tile_off;                // (ntiles+1) exclusive prefix of tile_count
+  uint32_t* large;                   // (total) global indices of primitives too big to bin
+  uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by tile
   SegDev seg[SRH_MAX_SEGMENTS];
   const float* lpos;
   const int32_t* lcidx;
@@ -132,6 +142,15 @@ __device__ __forceinline__ double hit_any64(int type, const double* R, const dou
 // a strictly smaller t, so the lowest global index wins ties exactly like np.argmin.
 __device__ __forceinline__ void resolve(const FrameDev& F, double t, int gidx, double& best, int& besti) {
   if (F.near_clip <= t && t <= F.far_clip && t < best) { best = t; besti = gidx; }
+}
+
+// Order-independent form of the same rule, for traversals that do not visit primitives in index order:
+// lexicographic minimum of (t, global index).
+__device__ __forceinline__ void resolve_lex(const FrameDev& F, double t, int gidx, double& best, int& besti) {
+  if (F.near_clip <= t && t <= F.far_clip && (t < best || (t == best && gidx < besti && besti != 0x7fffffff))) {
+    best = t;
+    besti = gidx;
+  }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

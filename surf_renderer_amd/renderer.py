@@ -63,8 +63,21 @@ class SceneBuffers:
     lights: _lib.SrhLights
     materials: _lib.SrhMaterials
     gamma: Optional[float]
-    workspace: torch.Tensor
+    workspace: Optional[torch.Tensor] = None   # per-frame scratch, sized for the largest frame seen so far
+    workspace_frame: Tuple[int, int] = (0, 0)
     total: int = 0
+
+    def ensure_workspace(self, width: int, height: int) -> torch.Tensor:
+        """Device scratch for libsrh (primitive records + tile bins) at ``width x height``."""
+        if self.workspace is None or width > self.workspace_frame[0] or height > self.workspace_frame[1]:
+            lib = _lib.load()
+            w, h = max(width, self.workspace_frame[0]), max(height, self.workspace_frame[1])
+            need = lib.srh_workspace_bytes(C.byref(self.objects), w, h)
+            if need == 0:
+                raise _lib.SrhError(-1, lib.srh_last_error().decode())
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.workspace_frame = (w, h)
+        return self.workspace
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors.values())
@@ -166,12 +179,8 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True) -
         g = tm["gamma"]
         gamma = float(g.detach().cpu().reshape(-1)[0]) if isinstance(g, torch.Tensor) else float(np.ravel(g)[0])
 
-    ws_bytes = lib.srh_workspace_bytes(C.byref(ob))
-    if ws_bytes == 0:
-        raise _lib.SrhError(-1, lib.srh_last_error().decode())
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     return SceneBuffers(device=device, kinds=kinds, counts=counts, tensors=tensors, objects=ob, lights=ls,
-                        materials=ms, gamma=gamma, workspace=workspace, total=sum(counts))
+                        materials=ms, gamma=gamma, total=sum(counts))
 
 
 def _shape_of(x):
@@ -255,9 +264,10 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                             depth_row_stride=depth.stride(0) if h > 1 else 0,
                             nearest_row_stride=nearest.stride(0) if (nearest is not None and h > 1) else 0,
                             ev_start=events.start if events else None, ev_stop=events.stop if events else None)
+    workspace = buf.ensure_workspace(width, height)
     with torch.cuda.device(buf.device):
         rc = lib.srh_render_fwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
-                                C.byref(params), buf.workspace.data_ptr(), buf.workspace.numel(),
+                                C.byref(params), workspace.data_ptr(), workspace.numel(),
                                 image.data_ptr(), depth.data_ptr(),
                                 nearest.data_ptr() if nearest is not None else None, _stream_ptr(buf.device))
     _lib.check(rc)
@@ -305,7 +315,7 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     +inf where nothing is hit, ``nearest`` (H,W) int64 (0 where nothing is hit), matching
     ``diffrend.numpy.renderer.render`` within fp32 rounding of the stored outputs.
 
-    Keyword arguments: ``device`` ('cuda'), ``mode`` ('auto' | 'exact' | 'fast'), ``rows`` ((r0, r1) slab),
+    Keyword arguments: ``device`` ('cuda'), ``mode`` ('auto' | 'exact' | 'fast' | 'binned'), ``rows`` ((r0, r1) slab),
     ``validate`` (host-side index / w checks).  The torch backend's kwargs (tiled, tile_size, shadow, ...)
     are accepted and ignored: the numpy backend this one matches has none of those features.
     """

@@ -40,7 +40,7 @@ def assert_parity(got, want, max_nearest_mismatch=0.0):
                                equal_nan=True)
 
 
-@pytest.mark.parametrize("mode", ["exact", "auto"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "binned"])
 @pytest.mark.parametrize("case", golden_cases())
 def test_golden(case, mode):
     scene, want, _ = load_case(os.path.join(GOLDEN_DIR, case + ".npz"))
@@ -73,3 +73,51 @@ def test_caller_scene_not_modified():
     for kind in scene["objects"]:
         for k, v in scene["objects"][kind].items():
             np.testing.assert_array_equal(v, before["objects"][kind][k])
+
+
+def _modes_identical(scene, modes=("exact", "fast", "binned")):
+    ref = _render(scene, mode=modes[0])
+    for mode in modes[1:]:
+        got = _render(scene, mode=mode)
+        for k in ("nearest", "depth", "image"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{mode} vs {modes[0]}: {k}")
+    return ref
+
+
+@pytest.mark.parametrize("builder", ["disk_cloud", "bunny_splat", "bunny_mesh", "mixed", "halfbox"])
+def test_modes_are_bit_identical(builder):
+    """The reject tests and the tile binning may only skip pairs that are misses: every mode must produce
+    the same bits as the all-pairs fp64 mode."""
+    from surf_renderer_amd import synthetic
+    scene = {
+        "disk_cloud": lambda: synthetic.disk_cloud_scene(20000, 640, 360, radius=0.03, seed=5),
+        "bunny_splat": lambda: synthetic.bunny_splat_scene(256, 256),
+        "bunny_mesh": lambda: synthetic.bunny_mesh_scene(256, 192),
+        "mixed": lambda: synthetic.demo_scene(333, 250, with_planes=True),
+        "halfbox": lambda: synthetic.json_scene("halfbox_sphere_cube.json", 320, 240),
+    }[builder]()
+    ref = _modes_identical(scene)
+    assert np.isfinite(ref["depth"]).mean() > 0.05
+
+
+def test_modes_identical_random_cameras():
+    """Discs seen edge-on, behind the camera, straddling the image border, from inside the cloud."""
+    from surf_renderer_amd import synthetic
+    rng = np.random.RandomState(11)
+    for trial in range(6):
+        scene = synthetic.disk_cloud_scene(3000, 200, 150, radius=float(rng.uniform(0.01, 0.3)), seed=100 + trial)
+        eye = rng.uniform(-1.5, 1.5, size=3)
+        scene["camera"]["eye"] = [float(eye[0]), float(eye[1]), float(eye[2]), 1.0]
+        scene["camera"]["at"] = [float(v) for v in rng.uniform(-0.3, 0.3, size=3)] + [1.0]
+        scene["camera"]["fovy"] = float(np.deg2rad(rng.uniform(20, 110)))
+        scene["camera"]["near"] = float(rng.choice([1e-3, 0.1, 0.5]))
+        _modes_identical(scene)
+
+
+def test_oracle_parity_mid_size():
+    """CPU oracle vs hip on a seeded scene larger than the goldens (fp64 oracle, a few seconds)."""
+    from surf_renderer_amd import synthetic
+    from surf_renderer_amd.scene import scene_to_numpy
+    scene = synthetic.disk_cloud_scene(1500, 160, 120, radius=0.06, seed=3)
+    want = np_oracle.render(scene_to_numpy(scene, round_fp32=True))
+    assert_parity(_render(scene), want)
