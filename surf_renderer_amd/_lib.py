@@ -68,7 +68,8 @@ class SrhError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    """In-tree libsrh.so; SRH_LIB points experiments (kernel A/B builds) at another build of the same ABI."""
+    return os.environ.get("SRH_LIB") or _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:

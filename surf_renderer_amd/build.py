@@ -14,7 +14,7 @@ INCLUDE = os.path.join(REPO, "include")
 LIB_PATH = os.path.join(PKG, "libsrh.so")
 
 SOURCES = [os.path.join(CSRC, "srh.hip")]
-HEADERS = [os.path.join(CSRC, "srh_device.h"), os.path.join(INCLUDE, "srh.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "srh.h")]
 
 # -ffp-contract=off: the fp64 truth path mirrors numpy's unfused arithmetic; kernels that want FMAs
 # ask for them explicitly.

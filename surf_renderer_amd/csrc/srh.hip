@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, 
     case SRH_PRIM_DISK: disk_reject_record(R, B, F.W, F.H, Q); break;
     case SRH_PRIM_SPHERE: sphere_reject_record(R, B, F.W, F.H, near_pos, Q); break;
     case SRH_PRIM_TRIANGLE: triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q); break;
-    default: rec_always(Q, kRec32Stride[SRH_PRIM_PLANE]); break;
+    default: plane_reject_record(R, B, F.W, F.H, Q); break;
   }
-  if (F.tilerange) bin_primitive(F, S.type, Q, S.first + i);
+  if (F.tilerange) bin_primitive(F, s, S.type, Q, S.first + i);
 }
 
 __device__ void prep_record64(const SegDev& S, int i, const double o[3], double* R) {
@@ -210,23 +210,35 @@ __global__ __launch_bounds__(256) void k_render_fast(FrameDev F, float* __restri
     const SegDev& S = F.seg[s];
     if (S.type == SRH_PRIM_DISK || S.type == SRH_PRIM_SPHERE) {
       for (int i = 0; i < S.count; ++i) {
-        const float* Q = S.rec32 + (size_t)i * 8;
+        const float* Q = S.rec32 + (size_t)i * kRec32Stride[SRH_PRIM_DISK];
         const float dr = rf - Q[1];
-        const float e = Q[3] * dr;
-        const float g = __builtin_fmaf(Q[4] * dr, dr, -1.0f);
         float q[P];
         float m = __builtin_inff();
+        if (Q[11] > 0.0f) {                    // elongated ellipse: principal-axes form (srh_reject.h)
+          const float eydr = Q[3] * dr, exdr = Q[2] * dr;
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-          const float dc = cf[j] - Q[0];
-          q[j] = __builtin_fmaf(dc, __builtin_fmaf(Q[2], dc, e), g);
-          m = fminf(m, q[j]);
+          for (int j = 0; j < P; ++j) {
+            const float dc = cf[j] - Q[0];
+            const float u = __builtin_fmaf(Q[2], dc, eydr) * Q[4];
+            const float v = __builtin_fmaf(-Q[3], dc, exdr) * Q[11];
+            q[j] = __builtin_fmaf(u, u, __builtin_fmaf(v, v, -1.0f));
+            m = fminf(m, q[j]);
+          }
+        } else {
+          const float e = Q[3] * dr;
+          const float g = __builtin_fmaf(Q[4] * dr, dr, -1.0f);
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            const float dc = cf[j] - Q[0];
+            q[j] = __builtin_fmaf(dc, __builtin_fmaf(Q[2], dc, e), g);
+            m = fminf(m, q[j]);
+          }
         }
         if (m <= 0.0f) confirm<P>(F, S, i, r, cbase, q, false, best, besti);
       }
     } else if (S.type == SRH_PRIM_TRIANGLE) {
       for (int i = 0; i < S.count; ++i) {
-        const float* Q = S.rec32 + (size_t)i * 12;
+        const float* Q = S.rec32 + (size_t)i * kRec32Stride[SRH_PRIM_TRIANGLE];
         const float r0 = __builtin_fmaf(Q[1], rf, Q[2]);
         const float r1 = __builtin_fmaf(Q[5], rf, Q[6]);
         const float r2 = __builtin_fmaf(Q[9], rf, Q[10]);
@@ -318,14 +330,14 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   }
   L.tiles_x = (width + kTile - 1) / kTile;
   L.tiles_y_max = (height + kTile - 1) / kTile;
-  const size_t ntiles = (size_t)L.tiles_x * L.tiles_y_max;
+  const size_t ntiles = ((size_t)L.tiles_x * L.tiles_y_max + 3) / 4 * 4;
   L.tilerange = off;
   off = align_up(off + total * 4 * sizeof(uint16_t));
   L.counters = off;
-  L.counters_bytes = (kCounterPad + 2 * ntiles) * sizeof(uint32_t);
+  L.counters_bytes = (kCounterPad + 2 * SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
   off = align_up(off + L.counters_bytes);
   L.tile_off = off;
-  off = align_up(off + (ntiles + 1) * sizeof(uint32_t));
+  off = align_up(off + (SRH_MAX_SEGMENTS * ntiles + 4) * sizeof(uint32_t));
   L.large = off;
   off = align_up(off + total * sizeof(uint32_t));
   L.entries = off;
@@ -468,13 +480,15 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     F.tiles_x = L.tiles_x;
     F.tiles_y = (F.row1 - F.row0 + kTile - 1) / kTile;
     F.ntiles = F.tiles_x * F.tiles_y;
+    F.ntiles_pad = (F.ntiles + 3) / 4 * 4;
+    F.nbins = F.nseg * F.ntiles_pad;
     char* ws = (char*)workspace;
     F.tilerange = (uint16_t*)(ws + L.tilerange);
     F.counters = (uint32_t*)(ws + L.counters);
     F.tile_off = (uint32_t*)(ws + L.tile_off);
     F.large = (uint32_t*)(ws + L.large);
     F.entries = (uint32_t*)(ws + L.entries);
-    hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.ntiles) * sizeof(uint32_t), st);
+    hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);
     if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
   }
 
@@ -485,11 +499,11 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
   if (mode == SRH_MODE_BINNED) {
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
-    hipLaunchKernelGGL(k_bin_fill, dim3((F.total + 255) / 256), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * 16 + 255) / 256)), dim3(256), 0, st, F);
   }
   if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {
-    hipLaunchKernelGGL(k_render_binned, dim3(F.tiles_x, F.tiles_y), dim3(256), 0, st, F, image, depth, nearest);
+    hipLaunchKernelGGL(k_render_binned, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);

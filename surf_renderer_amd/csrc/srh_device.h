@@ -43,12 +43,13 @@ struct FrameDev {
   int32_t nseg, total, nlights, ncolors, nmat, tonemap;
   int64_t img_stride, depth_stride, near_stride;   // elements per output row
   // tile binning (BINNED mode): 16x16-pixel tiles over the rendered row slab
-  int32_t tiles_x, tiles_y, ntiles, pad0;
+  int32_t tiles_x, tiles_y, ntiles, ntiles_pad;   // ntiles_pad = ntiles rounded up to a multiple of 4
+  int32_t nbins, pad1;                            // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile
   uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
-  uint32_t* counters;                // [0] n_large | [64, 64+ntiles) tile_count | [64+ntiles, 64+2 ntiles) cursor
-  uint32_t* tile_off;                // (ntiles+1) exclusive prefix of tile_count
-  uint32_t* large;                   // (total) global indices of primitives too big to bin
-  uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by tile
+  uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts | [64+nbins, 64+2 nbins) fill cursors
+  uint32_t* tile_off;                // (nbins+1) exclusive prefix of the bin counts
+  uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)
+  uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by bin
   SegDev seg[SRH_MAX_SEGMENTS];
   const float* lpos;
   const int32_t* lcidx;
@@ -67,7 +68,8 @@ __device__ __forceinline__ double dot3(const double* a, const double* b) {
 }
 
 // numpy/renderer.py:145-169 for pixel (column c, row r) of the full W x H grid.
-__device__ __forceinline__ void pixel_ray(const FrameDev& F, int c, int r, double d[3]) {
+// Returns |D|, the length of the un-normalised direction.
+__device__ __forceinline__ double pixel_ray(const FrameDev& F, int c, int r, double d[3]) {
   // np.linspace(-1, 1, W)[c], np.linspace(1, -1, H)[r]: start + i*step, last sample forced to stop
   const double xs = (F.W > 1 && c == F.W - 1) ? 1.0 : (c * F.step_x + -1.0);
   const double ys = (F.H > 1 && r == F.H - 1) ? -1.0 : (r * F.step_y + 1.0);
@@ -78,6 +80,7 @@ __device__ __forceinline__ void pixel_ray(const FrameDev& F, int c, int r, doubl
   const double len = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
 #pragma unroll
   for (int i = 0; i < 3; ++i) d[i] = v[i] / len;
+  return len;
 }
 
 // ---- intersections: return the reference's ray_distance for one (ray, primitive) pair ------------
@@ -155,38 +158,61 @@ __device__ __forceinline__ void resolve_lex(const FrameDev& F, double t, int gid
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// 1/sqrt(x) for x > 0 to ~1 ulp of fp64 without the IEEE sqrt + divide expansions: v_rsq_f64 seed and two
+// Newton steps.  Only the fragment stage uses it; its result is rounded to fp32 on output.
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+// image ** gamma of the tonemap (numpy/renderer.py:140-142) evaluated in fp32: x is already within half an
+// fp32 ulp of the reference value, powf adds ~2 ulp.
+__device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
+  return F.tonemap ? powf((float)v, (float)F.gamma) : (float)v;
+}
+
 // Fragment stage for one pixel (numpy/renderer.py:228-263): gathers the winner's normal / position /
 // albedo, Lambert over all lights with no per-light clamp (Q4, Q5), depth mask, clip, tonemap.
-// `z` is +inf and `win` 0 for an all-miss pixel, exactly what np.argmin hands the reference; the
-// garbage that produces is zeroed by the depth mask just as it is there.
+// `z` is +inf and `win` 0 for an all-miss pixel, exactly what np.argmin hands the reference; whatever
+// garbage the reference computes there is overwritten by the depth mask (:256), so masked pixels skip
+// the light loop and go straight to tonemap(0).
+// Arithmetic is fp64; vectors are normalised by multiplying with rsqrt_newton(|v|^2) instead of dividing
+// each component by sqrt(|v|^2) (equal to ~1e-16, immaterial after the fp32 store).
 __device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3], double z, int win,
                                             float rgb[3]) {
+  const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
+  if (masked) {
+    rgb[0] = rgb[1] = rgb[2] = tonemap_f32(F, 0.0);
+    return;
+  }
   int s = 0;
 #pragma unroll
   for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
     if (i < F.nseg && win >= F.seg[i].first) s = i;
   const SegDev& S = F.seg[s];
   const int li = win - S.first;
-  const double p[4] = {F.o[0] + z * d[0], F.o[1] + z * d[1], F.o[2] + z * d[2], 1.0 + z * 0.0};
+  const double p[3] = {F.o[0] + z * d[0], F.o[1] + z * d[1], F.o[2] + z * d[2]};
 
-  double n[4];
+  double n[3];
   if (S.type == SRH_PRIM_SPHERE) {
-    // (p - c) / |p - c|, zero where the ray's line misses the sphere (:45-47)
-    const float* c = S.pos + 4 * li;
-    const double v[4] = {p[0] - (double)c[0], p[1] - (double)c[1], p[2] - (double)c[2], p[3] - (double)c[3]};
-    const double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    // (p - c) / |p - c|, zero where the ray's line misses the sphere (:45-47); p == c gives nan as there
+    const float* c = S.pos + 4 * (size_t)li;
+    const double v[3] = {p[0] - (double)c[0], p[1] - (double)c[1], p[2] - (double)c[2]};
+    const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : (0.0 / len2);
     bool ok;
-    (void)hit_sphere64(S.rec64 + 4 * li, d, &ok);
+    (void)hit_sphere64(S.rec64 + 4 * (size_t)li, d, &ok);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) n[i] = ok ? v[i] / len : 0.0;
+    for (int i = 0; i < 3; ++i) n[i] = ok ? v[i] * inv : 0.0;
   } else {
-    // ops.normalize over all four components, zero vectors stay zero (numpy/ops.py:18-26)
-    const float* q = S.normal + 4 * li;
-    const double v[4] = {(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
-    double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
-    if (!(fabs(len) > 0.0)) len = 1.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n[i] = v[i] / len;
+    // unit normal as k_prep normalised it (ops.normalize, zero vectors stay zero, numpy/ops.py:18-26)
+    const double* R = S.rec64 + (size_t)li * kRec64Stride[S.type];
+    n[0] = R[0]; n[1] = R[1]; n[2] = R[2];
   }
   const int m = clampi(S.mat[li], 0, F.nmat - 1);
   const double alb[3] = {(double)F.albedo[3 * m], (double)F.albedo[3 * m + 1], (double)F.albedo[3 * m + 2]};
@@ -194,24 +220,20 @@ __device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3]
   double im[3] = {0.0, 0.0, 0.0};
   for (int l = 0; l < F.nlights; ++l) {
     const float* lp = F.lpos + 4 * l;
-    double v[4] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2], (double)lp[3] - p[3]};
-    double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
-    if (len <= 0.0) len = 1.0;                                    // Q7
-    const double ndotl = ((n[0] * (v[0] / len) + n[1] * (v[1] / len)) + n[2] * (v[2] / len)) + n[3] * (v[3] / len);
+    const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
+    const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    // |l| <= 0 -> 1 (Q7): the light sits exactly on the fragment and contributes n . 0 = 0
+    const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;
+    const double ndotl = ((n[0] * v[0] + n[1] * v[1]) + n[2] * v[2]) * inv;
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const double term = (ndotl * (double)F.colors[3 * ci + ch]) * alb[ch];
-      im[ch] = (l == 0) ? term : im[ch] + term;
-    }
+    for (int ch = 0; ch < 3; ++ch) im[ch] += (ndotl * (double)F.colors[3 * ci + ch]) * alb[ch];
   }
-  const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    double v = masked ? 0.0 : im[ch];
+    double v = im[ch];
     if (v < 0.0) v = 0.0;                                         // :259, NaN stays NaN
-    if (F.tonemap) v = pow(v, F.gamma);                           // :262-263
-    rgb[ch] = (float)v;
+    rgb[ch] = tonemap_f32(F, v);                                  // :262-263
   }
 }
 

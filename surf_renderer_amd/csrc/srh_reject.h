@@ -1,28 +1,39 @@
-// Conservative per-pair reject tests of the FAST / binned render modes (gfx950).
+// Screen-space reject records of the FAST / BINNED render modes (gfx950).
 //
 // For a pinhole camera the set of pixels whose ray *line* meets a disc (or a sphere) is the interior of
-// a conic in pixel coordinates, and the inside of a triangle is the intersection of three half planes.
-// k_prep derives those screen-space shapes per primitive and per frame in fp64, inflates them by a
-// margin that covers every fp32 rounding on the evaluation side, and stores them as fp32 "reject
-// records".  The render kernels evaluate the cheap fp32 test per (pixel, primitive) pair and send only
-// the survivors to the fp64 intersection of srh_device.h.  A pair that fails the reject test is provably
-// a miss of the fp64 test, so the output is bit-identical to the all-pairs fp64 mode.
+// a conic in pixel coordinates, the inside of a triangle is the intersection of three half planes, and
+// n^.D is affine in the pixel coordinates.  k_prep derives those screen-space shapes per primitive and per
+// frame in fp64, inflates them by a margin that covers every fp32 rounding on the evaluation side, and
+// stores them as fp32 "reject records".  The render kernels evaluate the cheap fp32 tests per
+// (pixel, primitive) pair and send only the survivors to the fp64 intersection of srh_device.h.  A pair
+// that fails a reject test is provably not the winner of the fp64 path, so every mode's output is
+// bit-identical to the all-pairs fp64 mode.
 //
 // Pixel coordinates are (c, r) = (column, row) indices of the full image; the un-normalised ray
 // direction is affine in them:  D(c, r) = D0 + c*Dc + r*Dr   (numpy/renderer.py:152-164).
 //
 // rec32 layouts (floats)
-//   disc, sphere [0] c0 [1] r0 [2] A11 [3] 2*A12 [4] A22  -> candidate iff
-//                dc*(A11*dc + 2A12*dr) + A22*dr*dr - 1 <= 0,  dc = c - c0, dr = r - r0
-//                (all zero = "always a candidate": discs whose image is not an ellipse, etc.)
-//   triangle     3 x {a, b, g, 0}: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
-//   plane        none: every pixel is a candidate
+//   disc (12)      [0] c0 [1] r0 [2] A11 [3] 2*A12 [4] A22 [11] 0 : candidate iff
+//                  dc*(A11*dc + 2A12*dr) + A22*dr*dr - 1 <= 0,  dc = c - c0, dr = r - r0
+//                  (A = 0: "always a candidate" -- the disc's image is not an ellipse, etc.)
+//                  elongated ellipses use [2] ex [3] ey [4] iu [11] iv > 0: candidate iff
+//                  (u*iu)^2 + (v*iv)^2 - 1 <= 0,  u = ex*dc + ey*dr, v = ex*dr - ey*dc
+//                  [5..7] v0 v1 v2 [8] k [9] E [10] Esolid : depth estimate, see below
+//   sphere (12)    [0..4] as the disc, rest unused
+//   triangle (16)  {a_i, b_i, g_i} at [4i..4i+2], i < 3: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
+//                  [3] v0 [7] v1 [11] v2 [12] k [13] E [14] Esolid
+//   plane (8)      [0..2] v0 v1 v2 [3] k [4] E [5] Esolid; every pixel is a candidate
+//
+// Depth estimate of a planar primitive (disc, triangle, plane): the ray distance is
+//   t = k |D| / (n^.D),   n^.D = v0 + c*v1 + r*v2   with v_j = n^.{D0, Dc, Dr}
+// E bounds the absolute fp32 error of the evaluated denominator; Esolid = 1024 E is the smallest |denominator|
+// for which the estimate is trusted.
 #pragma once
 #include "srh_device.h"
 
 namespace srh {
 
-constexpr int kRec32Stride[4] = {8, 4, 8, 12};
+constexpr int kRec32Stride[4] = {12, 8, 12, 16};
 
 struct PixelBasis {   // D(c,r) = D0 + c*Dc + r*Dr
   double D0[3], Dc[3], Dr[3];
@@ -38,42 +49,86 @@ __device__ __host__ inline PixelBasis pixel_basis(const FrameDev& F) {
   return B;
 }
 
-__device__ inline void rec_always(float* out, int n) {
+__device__ inline void rec_zero(float* out, int n) {
   for (int i = 0; i < n; ++i) out[i] = 0.0f;
 }
 
-// Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record.
-__device__ inline void conic_record(double T00, double T01, double T02, double T11, double T12, double T22,
-                                    int W, int H, float* out) {
-  rec_always(out, 8);
+// v0, v1, v2, k, E, Esolid of a planar primitive with unit normal n and plane offset k
+__device__ inline void plane_estimate_record(const double n[3], double k, const PixelBasis& B, int W, int H,
+                                             float* v0, float* v1, float* v2, float* kk, float* E, float* Es) {
+  const double a = dot3(n, B.D0), b = dot3(n, B.Dc), c = dot3(n, B.Dr);
+  // 2^-21 (|v0| + W|v1| + H|v2|): the three fp32-rounded coefficients and the two fmas, with 2x slack
+  double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H);
+  if (!isfinite(e) || !isfinite(k) || !(e < 1.0e30)) e = 1.0e30;   // never "solid": candidates get confirmed
+  *v0 = (float)a; *v1 = (float)b; *v2 = (float)c; *kk = (float)k;
+  *E = (float)e * 1.0000002f;
+  *Es = (float)(1024.0 * e) * 1.0000002f;
+}
+
+// Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4], out[11].
+// Returns the major semi-axis in pixels, or -1 (record = "always a candidate") when the conic is not a
+// well-conditioned ellipse: not positive definite, centre or size beyond 2^20 pixels, or axis ratio > 4096
+// (a disc seen edge-on; its parameters are then numerical noise).
+__device__ inline double conic_record(double T00, double T01, double T02, double T11, double T12, double T22,
+                                      int W, int H, float* out) {
+  rec_zero(out, 5);
+  out[11] = 0.0f;                                              // quadratic form unless set below
   const double det = T11 * T22 - T12 * T12;
-  if (!(T11 > 0.0) || !(det > 0.0) || !isfinite(T00 + T01 + T02 + T11 + T12 + T22)) return;
+  if (!(T11 > 0.0) || !(det > 0.0) || !isfinite(T00 + T01 + T02 + T11 + T12 + T22)) return -1.0;
   const double c0 = -(T22 * T01 - T12 * T02) / det;
   const double r0 = -(T11 * T02 - T12 * T01) / det;
   const double F0 = T00 + T01 * c0 + T02 * r0;                 // value at the centre, < 0 inside
-  if (!(F0 < 0.0)) return;
+  if (!(F0 < 0.0)) return -1.0;
   double A11 = T11 / -F0, A12 = T12 / -F0, A22 = T22 / -F0;
   const double mean = 0.5 * (A11 + A22), dev = sqrt(0.25 * (A11 - A22) * (A11 - A22) + A12 * A12);
   const double lmax = mean + dev, lmin = mean - dev;
-  if (!(lmin > 0.0) || !isfinite(lmax)) return;
+  if (!(lmin > 0.0) || !isfinite(lmax)) return -1.0;
   double smin = 1.0 / sqrt(lmax);
   const double smax = 1.0 / sqrt(lmin);
   const double far_lim = 1048576.0;
-  if (!(fabs(c0) < far_lim) || !(fabs(r0) < far_lim) || !(smax < far_lim)) return;
-  if (smax > 32.0 * smin) {            // thin sliver: the quadratic form would cancel badly in fp32
-    A11 = A22 = 1.0 / (smax * smax);   // -> bounding circle
+  if (!(fabs(c0) < far_lim) || !(fabs(r0) < far_lim) || !(smax < far_lim)) return -1.0;
+  if (!(smax <= 4096.0 * smin)) return -1.0;
+  double cond = (smax / smin) * (smax / smin);   // terms of the quadratic form reach cond * Q near the boundary
+  const double pos_err = 2.384185791015625e-7 * (fabs(c0) + fabs(r0) + W + H);   // 2^-22 (...), see below
+  if (smax > 8.0 * smin) {
+    // Elongated ellipse: the quadratic form would cancel in fp32, so the record holds the principal-axes form
+    //   u = ex*dc + ey*dr, v = ex*dr - ey*dc, candidate iff (u*iu)^2 + (v*iv)^2 - 1 <= 0     (out[11] = iv > 0)
+    // (ex, ey) = unit eigenvector of the small eigenvalue = direction of the major axis.
+    double vx = lmin - A22, vy = A12;
+    if (fabs(lmin - A11) > fabs(vx)) { vx = A12; vy = lmin - A11; }
+    const double vl = sqrt(vx * vx + vy * vy);
+    if (vl > 0.0 && isfinite(vl)) {
+      const double ex = vx / vl, ey = vy / vl;
+      // u, v carry the position error (x sqrt 2), the rounding of ex, ey and of the two fmas (< 2^-21 smax);
+      // scaling both semi-axes by 1 + rho/smin covers every point within rho of the ellipse
+      const double rho = 0.000244140625 + 3.0 * pos_err + 9.5367431640625e-7 * smax;
+      const double grow = (1.0 + rho / smin) * (1.0 + 1.9073486328125e-6);
+      out[0] = (float)c0;
+      out[1] = (float)r0;
+      out[2] = (float)ex;
+      out[3] = (float)ey;
+      out[4] = (float)(1.0 / (smax * grow));
+      out[11] = (float)(1.0 / (smin * grow));
+      return smax * grow;
+    }
+    A11 = A22 = 1.0 / (smax * smax);   // no usable axis direction: bounding circle
     A12 = 0.0;
     smin = smax;
+    cond = 1.0;
   }
-  // margin in pixels: covers fp32 rounding of c0, r0, the coefficients and the evaluation
-  const double delta = 0.015625 + 9.5367431640625e-7 * (fabs(c0) + fabs(r0) + W + H);
+  // Margins.  Position: c0, r0 are rounded to fp32 (2^-24 |c0|) and so is c - c0 (2^-24 (W + |c0|)), together
+  // < 2^-23 (|c0| + |r0| + W + H) pixels; delta doubles that and adds 2^-12 px.  Value: three rounded coefficients
+  // and five rounded operations on terms up to cond * Q, < 2^-20 cond relative; `rel` is four times that.
+  const double delta = 0.000244140625 + pos_err;
+  const double rel = 3.814697265625e-6 * cond;
   const double grow = 1.0 + delta / smin;
-  const double thr = grow * grow * (1.0 + 0.001953125);
+  const double thr = grow * grow * (1.0 + rel);
   out[0] = (float)c0;
   out[1] = (float)r0;
   out[2] = (float)(A11 / thr);
   out[3] = (float)(2.0 * A12 / thr);
   out[4] = (float)(A22 / thr);
+  return smax * sqrt(thr);
 }
 
 // disc: | oc (n.D) + k D |^2 <= r^2 (n.D)^2   (numpy/renderer.py:69,85-88 with t = k / (n.D))
@@ -89,14 +144,29 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
     for (int a = 0; a < 3; ++a) u[j][a] = oc[a] * nu[j] + k * P[j][a];
   }
   auto T = [&](int i, int j) { return dot3(u[i], u[j]) - r2 * nu[i] * nu[j]; };
-  conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
+  // Every hit lies on the disc, hence inside the sphere around its centre with its radius.  That sphere's
+  // silhouette is a robust, well-conditioned ellipse: it replaces the disc's own image when that is degenerate
+  // (seen edge-on) and it caps the disc ellipse's size, which must fit inside it.
+  float sph[12];
+  const double cq = dot3(oc, oc) - r2;
+  double w[3];
+  for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
+  auto Ts = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
+  const double s_sphere = conic_record(Ts(0, 0), Ts(0, 1), Ts(0, 2), Ts(1, 1), Ts(1, 2), Ts(2, 2), W, H, sph);
+  const double s_disc = conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
+  if (s_sphere > 0.0 && (s_disc < 0.0 || s_disc > 1.5 * s_sphere + 2.0)) {
+    for (int i = 0; i < 5; ++i) out[i] = sph[i];
+    out[11] = sph[11];
+  }
+  plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
 }
 
 // sphere: the ray's line meets it iff (oc.D)^2 - |D|^2 (|oc|^2 - r^2) >= 0   (numpy/renderer.py:20-25).
 // With near <= 0 a missed line yields the valid t = 0 (Q2), so nothing may be rejected.
 __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B, int W, int H, bool near_positive,
                                             float* out) {
-  if (!near_positive) { rec_always(out, 8); return; }
+  rec_zero(out, 12);
+  if (!near_positive) return;
   const double* oc = R;
   const double cq = R[3];
   const double* P[3] = {B.D0, B.Dc, B.Dr};
@@ -110,11 +180,12 @@ __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B
 // sign(k) * (s_i n + k m_i) . D >= 0 with m_i = n x e_i, s_i = (o - v_i) . m_i   (numpy/renderer.py:114-126)
 __device__ inline void triangle_reject_record(const double* R, const double o[3], const PixelBasis& B, int W, int H,
                                               bool near_positive, float* out) {
-  rec_always(out, 12);
+  rec_zero(out, 16);
   for (int i = 0; i < 3; ++i) out[4 * i + 2] = 1.0f;          // a = b = 0, g = 1: always a candidate
-  if (!near_positive) return;
   const double* n = R;
   const double k = R[3];
+  plane_estimate_record(n, k, B, W, H, out + 3, out + 7, out + 11, out + 12, out + 13, out + 14);
+  if (!near_positive) return;
   const double sg = (k > 0.0) ? 1.0 : ((k < 0.0) ? -1.0 : 0.0);
   for (int i = 0; i < 3; ++i) {
     const double* v = R + 4 + 3 * i;
@@ -128,18 +199,43 @@ __device__ inline void triangle_reject_record(const double* R, const double o[3]
     if (!(len > 0.0) || !isfinite(len) || !isfinite(g)) continue;
     a /= len; b /= len; g /= len;                             // signed distance to the edge line, pixels
     if (!(fabs(g) < 1.0e9)) continue;
-    g += 0.015625 + 9.5367431640625e-7 * (fabs(g) + W + H);
+    // fp32 evaluation of a*c + b*r + g with rounded a, b, g: error < 3 * 2^-24 (|g| + W + H); margin 2.7x that
+    g += 0.000244140625 + 4.76837158203125e-7 * (fabs(g) + W + H);
     out[4 * i + 0] = (float)a;
     out[4 * i + 1] = (float)b;
     out[4 * i + 2] = (float)g;
   }
 }
 
-}  // namespace srh
+__device__ inline void plane_reject_record(const double* R, const PixelBasis& B, int W, int H, float* out) {
+  rec_zero(out, 8);
+  plane_estimate_record(R, R[3], B, W, H, out + 0, out + 1, out + 2, out + 3, out + 4, out + 5);
+}
+
+// fp32 evaluation of the ellipse record for four pixels of one row: value <= 0 means "candidate".
+__device__ __forceinline__ void ellipse_reject4(const float* __restrict__ R, const float cf[4], float rf, float q[4]) {
+  const float dr = rf - R[1];
+  if (R[11] > 0.0f) {                                     // principal-axes form (wave-uniform branch)
+    const float eydr = R[3] * dr, exdr = R[2] * dr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dc = cf[j] - R[0];
+      const float u = __builtin_fmaf(R[2], dc, eydr) * R[4];
+      const float v = __builtin_fmaf(-R[3], dc, exdr) * R[11];
+      q[j] = __builtin_fmaf(u, u, __builtin_fmaf(v, v, -1.0f));
+    }
+  } else {
+    const float ee = R[3] * dr;
+    const float gg = __builtin_fmaf(R[4] * dr, dr, -1.0f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dc = cf[j] - R[0];
+      q[j] = __builtin_fmaf(dc, __builtin_fmaf(R[2], dc, ee), gg);
+    }
+  }
+}
 
 // ---- conservative pixel bounding boxes of the reject shapes (for tile binning) ------------------------
-namespace srh {
-
 struct BBox {
   double c0, c1, r0, r1;   // inclusive pixel range that contains every true hit of the primitive
   bool full;               // no useful bound: treat as covering the whole image
@@ -147,8 +243,15 @@ struct BBox {
 
 __device__ inline BBox bbox_full() { return BBox{0, 0, 0, 0, true}; }
 
-// Box of { dc*(A11*dc + B*dr) + A22*dr^2 <= 1 } from the *stored* record, one pixel of slack.
+// Box of the stored ellipse record (either form), one pixel of slack.
 __device__ inline BBox conic_bbox(const float* rec) {
+  if (rec[11] > 0.0f) {
+    const double ex = rec[2], ey = rec[3], a = 1.0 / (double)rec[4], b = 1.0 / (double)rec[11];
+    const double hc = sqrt(ex * ex * a * a + ey * ey * b * b), hr = sqrt(ey * ey * a * a + ex * ex * b * b);
+    if (!isfinite(hc) || !isfinite(hr)) return bbox_full();
+    return BBox{(double)rec[0] - hc - 1.0, (double)rec[0] + hc + 1.0, (double)rec[1] - hr - 1.0,
+                (double)rec[1] + hr + 1.0, false};
+  }
   const double A11 = rec[2], A12 = 0.5 * (double)rec[3], A22 = rec[4];
   const double det = A11 * A22 - A12 * A12;
   if (!(A11 > 0.0) || !(det > 0.0)) return bbox_full();

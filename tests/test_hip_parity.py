@@ -121,3 +121,15 @@ def test_oracle_parity_mid_size():
     scene = synthetic.disk_cloud_scene(1500, 160, 120, radius=0.06, seed=3)
     want = np_oracle.render(scene_to_numpy(scene, round_fp32=True))
     assert_parity(_render(scene), want)
+
+
+def test_reject_margins_stress():
+    """Many seeded disc clouds at a resolution where thousands of pixel centres fall within a hair of an ellipse
+    edge: the fp32 reject tests must never drop a pair the fp64 path accepts (binned == exact, bit for bit)."""
+    from surf_renderer_amd import synthetic
+    rng = np.random.RandomState(2024)
+    for trial in range(12):
+        n = int(rng.choice([500, 4000, 12000]))
+        scene = synthetic.disk_cloud_scene(n, 512, 384, radius=float(rng.choice([0.004, 0.02, 0.07])), seed=300 + trial)
+        scene["camera"]["eye"] = [float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(1.5, 6)), 1.0]
+        _modes_identical(scene, modes=("exact", "binned"))
