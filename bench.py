@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pixels", type=int, default=384, help="pixels in the CPU-baseline sample")
+    ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
     return ap.parse_args()
 
 

@@ -1,0 +1,88 @@
+"""Backend dispatcher the reference's README advertises but never implemented
+(`python diffrend/render.py --use [gl|np|tf|tch] --scene ...`, README.md:15 vs diffrend/render.py:12-24):
+
+    python -m surf_renderer_amd.render_cli --use hip --scene assets/scenes/basic.json --out_dir out/
+
+`--use hip` renders with this package; `--use np` / `--use tch` import the reference's own backends when a
+DiffRend checkout is importable (they are not part of this package).  Writes image.npy, depth.npy, nearest.npy and
+8-bit PNGs like diffrend/torch/render.py:121-129 does.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+BACKENDS = {"hip": "surf_renderer_amd.renderer", "np": "diffrend.numpy.renderer", "tch": "diffrend.torch.renderer"}
+
+
+def write_png(path: str, img: np.ndarray) -> None:
+    """Minimal 8-bit grey / RGB PNG writer (no imaging library in the image)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[..., None]
+    h, w, ch = img.shape
+    color = {1: 0, 3: 2}[ch]
+    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color, 0, 0, 0)) +
+                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def to_numpy(x) -> np.ndarray:
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--use", choices=sorted(BACKENDS), default="hip")
+    ap.add_argument("--scene", required=True, help="diffrend 0.1 JSON scene")
+    ap.add_argument("--out_dir", default="./render_samples")
+    ap.add_argument("--width", type=int)
+    ap.add_argument("--height", type=int)
+    ap.add_argument("--mode", default="auto", help="hip only: auto | exact | fast | binned")
+    args = ap.parse_args(argv)
+
+    from .scene import load_scene, scene_to_numpy
+    vp = (args.width, args.height) if args.width and args.height else None
+    scene = load_scene(args.scene, viewport=vp)
+    try:
+        backend = importlib.import_module(BACKENDS[args.use])
+    except ImportError as exc:
+        print(f"backend {args.use!r} is not importable here: {exc}", file=sys.stderr)
+        return 2
+    if args.use == "hip":
+        res = backend.render(scene, mode=args.mode)
+    elif args.use == "np":
+        res = backend.render(scene_to_numpy(scene))
+    else:
+        from diffrend.torch.render import make_torch_var
+        res = backend.render(make_torch_var(scene_to_numpy(scene)))
+
+    os.makedirs(args.out_dir, exist_ok=True)
+    image, depth = to_numpy(res["image"]).squeeze(), to_numpy(res["depth"]).squeeze()
+    np.save(os.path.join(args.out_dir, "image.npy"), image)
+    np.save(os.path.join(args.out_dir, "depth.npy"), depth)
+    if "nearest" in res:
+        np.save(os.path.join(args.out_dir, "nearest.npy"), to_numpy(res["nearest"]))
+    write_png(os.path.join(args.out_dir, "im.png"), np.uint8(255 * np.clip(np.nan_to_num(image), 0, 1)))
+    fin = np.isfinite(depth)
+    if fin.any():
+        lo, hi = depth[fin].min(), depth[fin].max()
+        norm = np.where(fin, (depth - lo) / max(hi - lo, 1e-30), 1.0)
+        write_png(os.path.join(args.out_dir, "depth.png"), np.uint8(255 * norm))
+    print(f"{args.use}: {image.shape[1]}x{image.shape[0]} -> {args.out_dir}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

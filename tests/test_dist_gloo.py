@@ -1,0 +1,84 @@
+"""Row-slab framing over torch.distributed with the gloo backend, world_size 2 (CPU).
+
+The hip kernel cannot run here, so each rank renders its slab with the CPU oracle standing in for the kernel;
+what is under test is the partition, the single-gather collection into strided (H, 4W) framebuffers, and that
+the assembled frame equals the full-frame render."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from surf_renderer_amd.dist import all_slabs, gather_rows, row_slab
+
+
+def test_row_slabs_partition_the_image():
+    for height in (1, 2, 7, 48, 2048):
+        for world in (1, 2, 3, 8):
+            slabs = all_slabs(height, world)
+            assert slabs[0][0] == 0 and slabs[-1][1] == height
+            for (a0, a1), (b0, b1) in zip(slabs, slabs[1:]):
+                assert a1 == b0 and a1 >= a0
+            sizes = [b - a for a, b in slabs]
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == height
+    with pytest.raises(ValueError):
+        row_slab(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, height, width, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import np_oracle
+        from surf_renderer_amd import synthetic
+        from surf_renderer_amd.scene import scene_to_numpy
+        scene = scene_to_numpy(synthetic.demo_scene(width, height, with_planes=True), round_fp32=True)
+        r0, r1 = row_slab(height, rank, world)
+        part = np_oracle.render(scene, rows=(r0, r1))
+        # the bench's framebuffer layout: one (rows, 4W) slab, [W x rgb | W x depth] per row
+        if rank == 0:
+            frame = torch.zeros((height, 4 * width), dtype=torch.float32)
+            slab = frame[r0:r1]
+        else:
+            frame = None
+            slab = torch.zeros((r1 - r0, 4 * width), dtype=torch.float32)
+        image = slab.as_strided((r1 - r0, width, 3), (4 * width, 3, 1), slab.storage_offset())
+        depth = slab.as_strided((r1 - r0, width), (4 * width, 1), slab.storage_offset() + 3 * width)
+        image.copy_(torch.from_numpy(part["image"].astype(np.float32)))
+        depth.copy_(torch.from_numpy(part["depth"].astype(np.float32)))
+        gather_rows(slab, frame, height, dst=0)
+        if rank == 0:
+            full = np_oracle.render(scene)
+            fb = frame.numpy()
+            got_img = fb[:, :3 * width].reshape(height, width, 3)
+            got_depth = fb[:, 3 * width:]
+            ok = np.array_equal(got_img, full["image"].astype(np.float32)) and \
+                np.array_equal(got_depth, full["depth"].astype(np.float32))
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [48, 37])          # equal slabs -> gather; ragged -> batched send/recv
+def test_two_rank_row_slab_gather(height):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, height, 40, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

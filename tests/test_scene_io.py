@@ -1,0 +1,119 @@
+"""Host-side scene / model IO against arrays captured from the reference's own loaders (the golden inputs
+of g3-g6 were produced by diffrend.model / diffrend.torch.render.load_scene, see oracle/gen_golden.py)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from oracle.golden_io import load_case
+from surf_renderer_amd import scene as sio
+from surf_renderer_amd import synthetic
+
+
+def _golden_scene(name):
+    return load_case(os.path.join(GOLDEN_DIR, name + ".npz"))[0]
+
+
+@pytest.mark.parametrize("golden,fname", [("g3_basic_json_64x64", "basic.json"),
+                                           ("g4_halfbox_sphere_cube_64x64", "halfbox_sphere_cube.json")])
+def test_json_scene_expansion_matches_reference_loader(golden, fname):
+    want = _golden_scene(golden)
+    got = synthetic.json_scene(fname, 64, 64)
+    tri_w, tri_g = want["objects"]["triangle"], got["objects"]["triangle"]
+    np.testing.assert_array_equal(tri_g["face"], tri_w["face"])           # scale -> rotate -> translate, fp32-rounded
+    np.testing.assert_array_equal(tri_g["normal"], tri_w["normal"])
+    np.testing.assert_array_equal(tri_g["material_idx"], tri_w["material_idx"])
+    assert tri_g["material_idx"].dtype.kind == "i"
+    assert list(got["objects"].keys()) == ["triangle"]
+    np.testing.assert_allclose(np.asarray(got["lights"]["pos"], dtype=float), want["lights"]["pos"])
+    assert got["camera"]["viewport"] == [0, 0, 64, 64]
+
+
+def test_bunny_splat_recipe_matches_reference_loader():
+    want = _golden_scene("g5_bunny_splat_64x64")["objects"]["disk"]
+    got = synthetic.bunny_splat_scene(64, 64)["objects"]["disk"]
+    for key in ("pos", "normal", "radius"):
+        np.testing.assert_array_equal(got[key], want[key])
+    assert got["radius"].ndim == 1 and got["pos"].shape == (4968, 4)
+
+
+def test_bunny_mesh_recipe_matches_reference_loader():
+    want = _golden_scene("g6_bunny_mesh_48x48")["objects"]["triangle"]
+    got = synthetic.bunny_mesh_scene(48, 48)["objects"]["triangle"]
+    np.testing.assert_array_equal(got["face"], want["face"])
+    np.testing.assert_array_equal(got["normal"], want["normal"])
+    assert got["face"].shape == (4968, 3, 4)
+
+
+def test_obj_loader_basics(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("# c\nv 0 0 0\nv  1 0   0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1\n\nf 3 2 1\n")
+    m = sio.load_obj(str(p))
+    assert m["v"].shape == (3, 3) and m["f"].tolist() == [[0, 1, 2], [2, 1, 0]]
+    spec = sio.obj_to_triangle_spec(m)
+    np.testing.assert_array_equal(spec["normal"], [[0, 0, 1, 0], [0, 0, -1, 0]])
+    np.testing.assert_array_equal(spec["face"][..., 3], 1.0)
+
+
+def test_degenerate_face_normal_stays_zero():
+    v = np.array([[0., 0, 0], [1, 0, 0], [2, 0, 0]])
+    np.testing.assert_array_equal(sio.face_normals(v, np.array([[0, 1, 2]])), [[0, 0, 0]])
+
+
+def test_splat_and_off_loaders(tmp_path):
+    s = tmp_path / "a.splat"
+    s.write_text("v 1 2 3\nvn 0 0 1\nr 0.5\nv 4 5 6\nvn 0 1 0\nr 0.25\n")
+    spl = sio.load_model(str(s))
+    assert spl["r"].shape == (2, 1) and spl["v"].shape == (2, 3) and spl["type"] == "splat"
+    o = tmp_path / "a.off"
+    o.write_text("OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    off = sio.load_model(str(o))
+    assert off["v"].shape == (3, 3) and off["f"].tolist() == [[0, 1, 2]]
+    with pytest.raises(ValueError):
+        sio.load_model(str(tmp_path / "a.ply"))
+
+
+def test_axis_angle_matrix_is_a_rotation():
+    rot = sio.axis_angle_matrix([1, 0, 0], np.deg2rad(60.0))
+    np.testing.assert_allclose(rot @ rot.T, np.eye(3), atol=1e-15)
+    np.testing.assert_allclose(rot @ [0, 1, 0], [0, np.cos(np.pi / 3), np.sin(np.pi / 3)], atol=1e-15)
+    np.testing.assert_allclose(sio.axis_angle_matrix([0, 0, 5], 0.3), sio.axis_angle_matrix([0, 0, 1], 0.3), atol=1e-15)
+
+
+def test_scene_to_numpy_copies_and_rounds():
+    sc = synthetic.demo_scene(8, 6, with_planes=True)
+    sc["objects"]["disk"]["pos"] = (np.asarray(sc["objects"]["disk"]["pos"]) + 1e-9).tolist()
+    before = copy.deepcopy(sc)
+    out = sio.scene_to_numpy(sc, round_fp32=True)
+    assert sc["objects"]["disk"]["pos"] == before["objects"]["disk"]["pos"]
+    pos = out["objects"]["disk"]["pos"]
+    np.testing.assert_array_equal(pos, pos.astype(np.float32).astype(np.float64))
+    assert list(out["objects"].keys()) == list(sc["objects"].keys())
+    assert out["objects"]["disk"]["material_idx"].dtype == np.int64
+    with pytest.raises(ValueError):
+        sio.scene_to_numpy({**sc, "objects": {"obj": []}})
+
+
+def test_camera_frame_quirks():
+    cam = synthetic.demo_scene(64, 48)["camera"]
+    fr = sio.camera_frame(cam)
+    assert (fr.width, fr.height) == (64, 48)
+    np.testing.assert_allclose(np.linalg.norm(fr.by), 1.0)
+    assert abs(np.linalg.norm(fr.bx) - 1.0) > 1e-3          # Q1: x = cross(y, z) is not re-normalised
+    np.testing.assert_allclose(fr.half_w / fr.half_h, 64 / 48)
+    bad = dict(cam, eye=[0, 1, 10, 2.0])
+    with pytest.raises(ValueError):
+        sio.camera_frame(bad)
+
+
+def test_disk_cloud_is_seeded_and_fp32_representable():
+    a = synthetic.disk_cloud_scene(500, 32, 32)
+    b = synthetic.disk_cloud_scene(500, 32, 32)
+    for key in ("pos", "normal", "radius"):
+        np.testing.assert_array_equal(a["objects"]["disk"][key], b["objects"]["disk"][key])
+        arr = a["objects"]["disk"][key]
+        np.testing.assert_array_equal(arr, arr.astype(np.float32).astype(np.float64))
+    assert np.all(a["objects"]["disk"]["normal"][:, 2] >= 0)
+    np.testing.assert_allclose(np.linalg.norm(a["objects"]["disk"]["normal"][:, :3], axis=1), 1.0, atol=1e-6)
