@@ -109,31 +109,50 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
 
 // ---- render: one wave per 16x16-pixel tile, four pixels (one row quad) per lane ---------------------------------
 //
-// sweep     wave-uniform loop over a list: per (pixel, primitive) pair the fp32 screen-space reject, and for
-//           the survivors an fp32 LOWER BOUND of the ray distance, t ~ k |D| / (v0 + c v1 + r v2) minus its error
-//           bound.  Per pixel only the smallest bound (with its primitive) and the second smallest are kept.
-// confirm   the front candidate of every pixel goes through the fp64 intersection.  If the second smallest bound
-//           exceeds that confirmed depth nobody else can win or tie and the pixel is done -- the common case.
-// re-sweep  otherwise (a wave-level vote) the lists are walked again and every candidate whose bound still
-//           reaches the confirmed depth is confirmed as well.
-// A candidate is skipped only when its lower bound exceeds an exactly confirmed depth, so the output equals
-// the all-pairs fp64 mode bit for bit.
+// sweep     wave-uniform loop over the tile's lists, fp32 only: per (pixel, primitive) pair the screen-space
+//           reject and, for the survivors, a LOWER BOUND of the ray distance (plane_estimate_record).  Per pixel
+//           the four smallest bounds are kept (packed keys, see QuadState); a candidate without a usable
+//           bound counts as bound 0.  List words and reject records are wave-uniform: they arrive by
+//           scalar loads, software-pipelined one record and two list words ahead.  No fp64 in this loop.
+// finish    per pixel (state parked in LDS so only one pixel's fp64 state is live): the front candidate goes
+//           through the fp64 intersection; the second and third too while their bound still reaches the depth
+//           confirmed so far (a near miss at an ellipse edge, or nearly coplanar primitives).  If the fourth
+//           bound lies above the confirmed depth nobody else can win or tie.  Then shade and store.
+// slow path (very rare) for a pixel whose fourth bound reaches the confirmed depth the whole wave walks the tile's lists
+//           again, 64 entries at a time, confirms every other candidate that is unbounded or whose bound reaches
+//           the confirmed depth, and merges the results with a wavefront-shuffle lexicographic minimum.
+// A candidate is skipped only when its lower bound exceeds an exactly confirmed depth, so it can neither win nor
+// tie: the output equals the all-pairs fp64 mode bit for bit.
+// Per pixel the sweep keeps the four smallest KEYS.  A key packs a candidate's depth lower bound and its
+// position in the tile's lists into one 32-bit word so that tracking is four integer min/median operations:
+//   key = (bits(lo) & ~0xFFF) | ordinal      lo > 0 finite: its bit pattern orders like the value, and clearing
+//                                            the low 12 mantissa bits only lowers it -- still a lower bound
+//   key = ordinal                            candidate without a usable bound ("bound 0": confirmed directly)
+//   key = 0xFFFFFFFF                         not a candidate
+// ordinal = index of the primitive in the concatenation of the tile's lists, saturated at 4095 (a pixel whose
+// front keys carry the saturated ordinal takes the slow path).
+constexpr uint32_t kOrdMask = 0xFFFu;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
 struct QuadState {
   float cf[4];        // pixel columns as fp32 (exact integers)
   float rf;           // pixel row
   float len[4];       // |D| of the un-normalised ray direction
-  float lo1[4];       // smallest depth lower bound seen
-  float lo2[4];       // second smallest
-  int g1[4];          // global index of the primitive with bound lo1, -1 = none
-  float bound[4];     // fp32 value >= the confirmed fp64 depth (re-sweep only)
-  bool again[4];      // pixel takes part in the re-sweep
+  uint32_t k1[4], k2[4], k3[4], k4[4];   // four smallest keys, ascending
 };
+
+// median of three (LLVM folds this pattern into one v_med3_u32)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  return max(min(a, b), min(max(a, b), c));
+}
+
+__device__ __forceinline__ float key_bound(uint32_t key) { return __uint_as_float(key & ~kOrdMask); }
 
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
 __device__ __forceinline__ float float_above(double t) { return (float)t * 1.0000005f; }
 
-__device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, const double d[3],
-                                                         double& best, int& besti) {
+__device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, const double d[3], double& best,
+                                               int& besti) {
   const int s = segment_of(F, gidx);
   int type = F.seg[0].type, first = F.seg[0].first;
   const double* base = F.seg[0].rec64;
@@ -161,222 +180,347 @@ struct RejectRecord {
   __device__ __forceinline__ float operator[](int i) const { return v[i]; }
 };
 
-// Per pixel: is the pair a candidate (passes the screen-space reject), and if so an fp32 lower bound `lo` of
-// its ray distance, or `loose` = no usable bound (grazing plane, sphere, near <= 0): must be confirmed.
-// Planar depth estimate: t = k |D| / den with den = v0 + c v1 + r v2; E bounds the fp32 error of den, and
-// only |den| >= Esolid = 1024 E is trusted, where the relative error of t is below E/|den| + 2^-20.
-// t <= 0 with a trusted den is provably not a valid hit (near > 0): the pair is dropped.
-template <int TYPE, bool PRETEST>
-__device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const QuadState& Q, bool cand[4],
-                                            bool loose[4], float lo[4]) {
-  float den[4], klen[4];
-  float E = 0.0f, Esolid = 0.0f;
+// N pixels of one row (columns cf[0..N-1], row rf, direction lengths len[]) against one reject record:
+//   cand[j]   passes the screen-space reject and has a trusted depth lower bound lo[j] (> 0)
+//   loose[j]  passes the reject but has no usable bound (grazing plane, sphere, near <= 0): must be confirmed
+// A pair that is neither is provably not a valid hit.
+template <int TYPE, bool PRETEST, int N>
+__device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const float (&cf)[N], float rf,
+                                            const float (&len)[N], bool (&cand)[N], bool (&loose)[N],
+                                            float (&lo)[N]) {
+  float den[N];
+  float kk = 0.0f, lo_den = 0.0f, hi_den = 0.0f;
   if (TYPE == SRH_PRIM_DISK || TYPE == SRH_PRIM_SPHERE) {
-    float q[4];
-    ellipse_reject4(R.v, Q.cf, Q.rf, q);
+    float q[N];
+    ellipse_reject<N>(R.v, cf, rf, q);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cand[j] = q[j] <= 0.0f;
+    for (int j = 0; j < N; ++j) cand[j] = q[j] <= 0.0f;
     if (TYPE == SRH_PRIM_DISK) {
-      const float rowden = __builtin_fmaf(R[7], Q.rf, R[5]);
+      const float rowden = __builtin_fmaf(R[7], rf, R[5]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { den[j] = __builtin_fmaf(R[6], Q.cf[j], rowden); klen[j] = R[8] * Q.len[j]; }
-      E = R[9]; Esolid = R[10];
+      for (int j = 0; j < N; ++j) den[j] = __builtin_fmaf(R[6], cf[j], rowden);
+      kk = R[8]; lo_den = R[9]; hi_den = R[10];
     }
   } else if (TYPE == SRH_PRIM_TRIANGLE) {
-    const float r0 = __builtin_fmaf(R[1], Q.rf, R[2]);
-    const float r1 = __builtin_fmaf(R[5], Q.rf, R[6]);
-    const float r2 = __builtin_fmaf(R[9], Q.rf, R[10]);
-    const float rowden = __builtin_fmaf(R[11], Q.rf, R[3]);
+    const float r0 = __builtin_fmaf(R[1], rf, R[2]);
+    const float r1 = __builtin_fmaf(R[5], rf, R[6]);
+    const float r2 = __builtin_fmaf(R[9], rf, R[10]);
+    const float rowden = __builtin_fmaf(R[11], rf, R[3]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float e0 = __builtin_fmaf(R[0], Q.cf[j], r0);
-      const float e1 = __builtin_fmaf(R[4], Q.cf[j], r1);
-      const float e2 = __builtin_fmaf(R[8], Q.cf[j], r2);
+    for (int j = 0; j < N; ++j) {
+      const float e0 = __builtin_fmaf(R[0], cf[j], r0);
+      const float e1 = __builtin_fmaf(R[4], cf[j], r1);
+      const float e2 = __builtin_fmaf(R[8], cf[j], r2);
       cand[j] = fminf(fminf(e0, e1), e2) >= 0.0f;
-      den[j] = __builtin_fmaf(R[7], Q.cf[j], rowden);
-      klen[j] = R[12] * Q.len[j];
+      den[j] = __builtin_fmaf(R[7], cf[j], rowden);
     }
-    E = R[13]; Esolid = R[14];
+    kk = R[12]; lo_den = R[13]; hi_den = R[14];
   } else {
-    const float rowden = __builtin_fmaf(R[2], Q.rf, R[0]);
+    const float rowden = __builtin_fmaf(R[2], rf, R[0]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < N; ++j) {
       cand[j] = true;
-      den[j] = __builtin_fmaf(R[1], Q.cf[j], rowden);
-      klen[j] = R[3] * Q.len[j];
+      den[j] = __builtin_fmaf(R[1], cf[j], rowden);
     }
-    E = R[4]; Esolid = R[5];
+    kk = R[3]; lo_den = R[4]; hi_den = R[5];
   }
   if (!PRETEST || TYPE == SRH_PRIM_SPHERE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { loose[j] = cand[j]; lo[j] = 0.0f; }
+    for (int j = 0; j < N; ++j) { loose[j] = cand[j]; cand[j] = false; lo[j] = 0.0f; }
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float inv = __builtin_amdgcn_rcpf(den[j]);
-    const float t = klen[j] * inv;
-    const float eps = __builtin_fmaf(E, fabsf(inv), 9.5367431640625e-7f);            // E/|den| + 2^-20
-    lo[j] = __builtin_fmaf(-t, eps, t);
-    const bool solid = fabsf(den[j]) >= Esolid;
-    loose[j] = cand[j] && !solid;
-    cand[j] = cand[j] && solid && t > 0.0f;
+  for (int j = 0; j < N; ++j) {
+    lo[j] = (kk * len[j]) * __builtin_amdgcn_rcpf(den[j]);
+    loose[j] = cand[j] && den[j] < lo_den && den[j] > hi_den;
+    cand[j] = cand[j] && den[j] >= lo_den;
   }
 }
 
-// LIST_INDEXED: `list` holds global primitive indices, records are fetched from the batch's rec32 array.
-template <int TYPE, bool RESWEEP, bool PRETEST>
-__device__ __forceinline__ void sweep_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
-                                           uint32_t n, QuadState& Q, const double (&d)[4][3],
-                                           double (&best)[4], int (&besti)[4]) {
-  const float inf = __builtin_inff();
+// The hot loop: fp32 only, straight-line, updates the per-pixel keys.  `ord0` = ordinal of the list's first entry.
+template <int TYPE, bool PRETEST>
+__device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n,
+                                           uint32_t ord0, QuadState& Q) {
   if (n == 0) return;
-  // software pipeline: the record of entry i+1 is in flight while entry i is evaluated
   int g_next = (int)list[0];
+  int g_next2 = (int)list[n > 1 ? 1 : 0];
   RejectRecord<TYPE> R_next;
   R_next.load(S.rec32 + (size_t)(g_next - S.first) * kRec32Stride[TYPE]);
   for (uint32_t i = 0; i < n; ++i) {
-    const int g = g_next;
     const RejectRecord<TYPE> R = R_next;
     if (i + 1 < n) {
-      g_next = (int)list[i + 1];
+      g_next = g_next2;
       R_next.load(S.rec32 + (size_t)(g_next - S.first) * kRec32Stride[TYPE]);
+      g_next2 = (int)list[i + 2 < n ? i + 2 : i + 1];
     }
+    const uint32_t ord = min(ord0 + i, kOrdMask);
     bool cand[4], loose[4];
     float lo[4];
-    pair_bounds<TYPE, PRETEST>(R, Q, cand, loose, lo);
-    const bool any_loose = loose[0] || loose[1] || loose[2] || loose[3];
-    if (!RESWEEP) {
-      // candidates without a usable bound are confirmed on the spot: rare, and it keeps them from posing as
-      // every pixel's front candidate
-      if (any_loose) {
+    pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, loose, lo);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (loose[j]) confirm_global(F, g, d[j], best[j], besti[j]);
-      }
-      const bool any_cand = cand[0] || cand[1] || cand[2] || cand[3];
-      if (__builtin_amdgcn_ballot_w64(any_cand) == 0ull) continue;       // wave-uniform skip
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x = cand[j] ? lo[j] : inf;
-        const bool front = x < Q.lo1[j];
-        Q.lo2[j] = __builtin_amdgcn_fmed3f(Q.lo1[j], x, Q.lo2[j]);
-        Q.lo1[j] = fminf(Q.lo1[j], x);
-        Q.g1[j] = front ? g : Q.g1[j];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (Q.again[j] && cand[j] && lo[j] <= Q.bound[j] && g != Q.g1[j]) {
-          confirm_global(F, g, d[j], best[j], besti[j]);
-          Q.bound[j] = float_above(best[j]);
-        }
-      }
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t ranked = (__float_as_uint(lo[j]) & ~kOrdMask) | ord;
+      const uint32_t key = loose[j] ? ord : (cand[j] ? ranked : kNoKey);
+      Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
+      Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
+      Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
+      Q.k1[j] = min(Q.k1[j], key);
     }
   }
 }
 
-template <bool RESWEEP, bool PRETEST>
-__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q,
-                                           const double (&d)[4][3], double (&best)[4], int (&besti)[4]) {
-  // per object batch: its frame-wide `large` primitives, then this tile's bin
+// Slow path, one pixel at a time, the whole wave helping: the pixel's state is broadcast, lane l examines list
+// entries l, l+64, ... (vector loads this time) and confirms those that are unbounded or whose bound reaches the
+// pixel's confirmed depth; the per-lane results are merged with a lexicographic (t, index) minimum over the wave
+// by cross-lane shuffles.
+struct SlowPixel {
+  float cf[1], len[1];
+  float rf;
+  float bound;        // fp32 value >= the depth confirmed so far
+  int g1, g2;         // already confirmed
+};
+
+template <int TYPE, bool PRETEST>
+__device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
+                                          uint32_t n, int lane, const SlowPixel& P, const double d[3],
+                                          double& best, int& besti) {
+  for (uint32_t i = lane; i < n; i += 64) {
+    const int g = (int)list[i];
+    RejectRecord<TYPE> R;
+    R.load(S.rec32 + (size_t)(g - S.first) * kRec32Stride[TYPE]);
+    bool cand[1], loose[1];
+    float lo[1];
+    pair_bounds<TYPE, PRETEST, 1>(R, P.cf, P.rf, P.len, cand, loose, lo);
+    if ((loose[0] || (cand[0] && lo[0] <= P.bound)) && g != P.g1 && g != P.g2) confirm_global(F, g, d, best, besti);
+  }
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __shfl_xor((unsigned)u, mask), hi = __shfl_xor((unsigned)(u >> 32), mask);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// The lists of a tile: per object batch its frame-wide `large` primitives (pass 0), then the tile's bin (pass 1).
+struct TileLists {
+  const FrameDev& F;
+  int tile;
+  __device__ __forceinline__ const uint32_t* list(int s, int pass) const {
+    return pass == 0 ? F.large + F.seg[s].first : F.entries + F.tile_off[s * F.ntiles_pad + tile];
+  }
+  __device__ __forceinline__ uint32_t count(int s, int pass) const {
+#ifdef SRH_ABL_NOLOOP
+    return 0;
+#else
+    const int bin = s * F.ntiles_pad + tile;
+    return pass == 0 ? F.counters[s] : F.tile_off[bin + 1] - F.tile_off[bin];
+#endif
+  }
+};
+
+template <bool PRETEST>
+__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q) {
+  const TileLists L{F, tile};
+  uint32_t ord0 = 0;
   for (int s = 0; s < F.nseg; ++s) {
     const SegDev& S = F.seg[s];
-    const int bin = s * F.ntiles_pad + tile;
-    const uint32_t lo = F.tile_off[bin], hi = F.tile_off[bin + 1];
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      const uint32_t* list = pass == 0 ? F.large + S.first : F.entries + lo;
-#ifdef SRH_ABL_NOLOOP
-      const uint32_t n = 0;
-#else
-      const uint32_t n = pass == 0 ? F.counters[s] : hi - lo;
-#endif
+      const uint32_t* list = L.list(s, pass);
+      const uint32_t n = L.count(s, pass);
       switch (S.type) {
-        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, RESWEEP, PRETEST>(F, S, list, n, Q, d, best, besti); break;
-        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, RESWEEP, PRETEST>(F, S, list, n, Q, d, best, besti); break;
-        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, RESWEEP, PRETEST>(F, S, list, n, Q, d, best, besti); break;
-        default: sweep_list<SRH_PRIM_TRIANGLE, RESWEEP, PRETEST>(F, S, list, n, Q, d, best, besti); break;
+        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST>(S, list, n, ord0, Q); break;
+        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST>(S, list, n, ord0, Q); break;
+        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST>(S, list, n, ord0, Q); break;
+        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST>(S, list, n, ord0, Q); break;
       }
+      ord0 += n;
     }
   }
 }
+
+// Global primitive index of the entry with ordinal `ord` (per lane) in the tile's lists; -1 if out of range.
+__device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, uint32_t ord) {
+  const TileLists L{F, tile};
+  int g = -1;
+  bool done = false;
+  for (int s = 0; s < F.nseg; ++s) {
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t n = L.count(s, pass);
+      if (!done && ord < n) { g = (int)L.list(s, pass)[ord]; done = true; }
+      if (!done) ord -= n;
+    }
+  }
+  return g;
+}
+
+// Resolve the pixel of lane `src` on the slow path with the whole wave; returns the merged (t, index) minimum of
+// everything confirmed here (index 0x7fffffff = nothing), valid in every lane.
+template <bool PRETEST>
+__device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane, int src, float cf, float rf,
+                                           float len, float bound, int g1, int g2, const double d[3],
+                                           double& out_t, int& out_i) {
+  SlowPixel P;
+  P.cf[0] = readlane_f32(cf, src);
+  P.rf = readlane_f32(rf, src);
+  P.len[0] = readlane_f32(len, src);
+  P.bound = readlane_f32(bound, src);
+  P.g1 = __builtin_amdgcn_readlane(g1, src);
+  P.g2 = __builtin_amdgcn_readlane(g2, src);
+  const double ds[3] = {readlane_f64(d[0], src), readlane_f64(d[1], src), readlane_f64(d[2], src)};
+  double best = __builtin_inf();
+  int besti = 0x7fffffff;
+  const TileLists L{F, tile};
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t* list = L.list(s, pass);
+      const uint32_t n = L.count(s, pass);
+      switch (S.type) {
+        case SRH_PRIM_DISK: slow_list<SRH_PRIM_DISK, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_PLANE: slow_list<SRH_PRIM_PLANE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_SPHERE: slow_list<SRH_PRIM_SPHERE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
+        default: slow_list<SRH_PRIM_TRIANGLE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {         // wavefront-shuffle lexicographic minimum of (t, index)
+    const double ot = shfl_xor_f64(best, m);
+    const int oi = __shfl_xor(besti, m);
+    if (ot < best || (ot == best && oi < besti)) { best = ot; besti = oi; }
+  }
+  out_t = best;
+  out_i = besti;
+}
+
+// per-pixel result of the sweep, parked in LDS between the sweep and the finish phase
+struct alignas(16) Parked {
+  uint32_t k1, k2, k3, k4;
+};
 
 __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte accesses
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  if (tile >= F.ntiles) return;               // waves are independent: no LDS, no barrier
+  if (tile >= F.ntiles) return;               // waves are independent: no barrier below, LDS slices are per wave
   const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
   const int c0 = tx * kTile + 4 * (lane & 3);
   const int r_raw = F.row0 + ty * kTile + (lane >> 2);
   const int r = min(r_raw, F.row1 - 1);
-  QuadState Q;
-  Q.rf = (float)r;
-  double d[4][3];
-  double best[4];
-  int besti[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = min(c0 + j, F.W - 1);
-    Q.cf[j] = (float)c;
-    Q.len[j] = (float)pixel_ray(F, c, r, d[j]);
-    Q.lo1[j] = Q.lo2[j] = __builtin_inff();
-    Q.g1[j] = -1;
-    best[j] = __builtin_inf();
-    besti[j] = 0x7fffffff;
-  }
 #ifdef SRH_ABL_NOPRETEST
   const bool pretest = false;
 #else
   const bool pretest = F.near_clip > 0.0;     // with near <= 0 a negative t can be valid: confirm every candidate
 #endif
-
-  if (pretest) sweep_tile<false, true>(F, tile, Q, d, best, besti);
-  else sweep_tile<false, false>(F, tile, Q, d, best, besti);
-
-  bool any_again = false;
-#ifndef SRH_ABL_NOCONFIRM
+  {
+    QuadState Q;
+    Q.rf = (float)r;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    Q.again[j] = false;
-    Q.bound[j] = float_above(best[j]);        // depth confirmed on the spot during the sweep, or +inf
-    if (Q.g1[j] >= 0 && Q.lo1[j] <= Q.bound[j]) {
-      confirm_global(F, Q.g1[j], d[j], best[j], besti[j]);
-      Q.bound[j] = float_above(best[j]);
-      Q.again[j] = Q.lo2[j] <= Q.bound[j];    // somebody else's bound still reaches the confirmed depth
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(c0 + j, F.W - 1);
+      double dtmp[3];
+      Q.cf[j] = (float)c;
+      Q.len[j] = (float)pixel_ray(F, c, r, dtmp);
+      Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
-    any_again = any_again || Q.again[j];
+    if (pretest) sweep_tile<true>(F, tile, Q);
+    else sweep_tile<false>(F, tile, Q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Parked p;
+      p.k1 = Q.k1[j]; p.k2 = Q.k2[j]; p.k3 = Q.k3[j]; p.k4 = Q.k4[j];
+      park[wave][j][lane] = p;
+    }
   }
-#endif
-#ifndef SRH_ABL_NORESWEEP
-  if (__builtin_amdgcn_ballot_w64(any_again) != 0ull) sweep_tile<true, true>(F, tile, Q, d, best, besti);
-#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   const bool row_live = r_raw < F.row1;
   const size_t row = (size_t)(r - F.row0);
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < 4; ++j) {
-    if (besti[j] == 0x7fffffff) besti[j] = 0;             // nothing hit: np.argmin of an all-inf column
+    const Parked p = park[wave][j][lane];
+    const int c = min(c0 + j, F.W - 1);
+    double d[3];
+    const float len = (float)pixel_ray(F, c, r, d);
+    double best = __builtin_inf();
+    int besti = 0x7fffffff;
+    float bound = __builtin_inff();
+    int g1 = -1, g2 = -1;
+    bool slow = false;
+#ifndef SRH_ABL_NOCONFIRM
+    if (p.k1 != kNoKey) {
+      // Confirm the front candidates in key order while their bound still reaches the confirmed depth (the
+      // first one always; the next ones after a near miss at an ellipse edge or for nearly coplanar primitives).
+      // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
+      const uint32_t keys[3] = {p.k1, p.k2, p.k3};
+      bool saturated = false;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const uint32_t key = keys[q];
+        if (key != kNoKey && !saturated && key_bound(key) <= bound) {
+          if ((key & kOrdMask) == kOrdMask) {
+            saturated = true;
+          } else {
+            const int g = ordinal_to_global(F, tile, key & kOrdMask);
+            if (q == 0) g1 = g;
+            if (q == 1) g2 = g;
+            confirm_global(F, g, d, best, besti);
+            bound = float_above(best);
+          }
+        }
+      }
+      // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
+      slow = saturated || (p.k4 != kNoKey && key_bound(p.k4) <= bound);
+      if (slow) { g1 = g2 = -1; }             // the slow path re-confirms; cheaper than excluding three indices
+    }
+#endif
+#ifndef SRH_ABL_NORESWEEP
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(slow);
+    while (todo) {                            // wave-uniform loop over the lanes whose pixel needs the slow path
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      double st;
+      int si;
+      if (pretest) slow_pixel<true>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+      else slow_pixel<false>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+      if (lane == src && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
+        best = st;
+        besti = si;
+      }
+    }
+#endif
+    if (besti == 0x7fffffff) besti = 0;       // nothing hit: np.argmin of an all-inf column
     float rgb[3];
 #ifdef SRH_ABL_NOSHADE
-    rgb[0] = rgb[1] = rgb[2] = (float)d[j][0] + Q.lo1[j];
+    rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __uint_as_float(p.k1);
 #else
-    shade_pixel(F, d[j], best[j], besti[j], rgb);
+    shade_pixel(F, d, best, besti, rgb);
 #endif
-    const int c = c0 + j;
-    if (row_live && c < F.W) {
-      float* px = image + row * F.img_stride + 3 * (size_t)c;
+    if (row_live && c0 + j < F.W) {
+      float* px = image + row * F.img_stride + 3 * (size_t)(c0 + j);
       px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
-      depth[row * F.depth_stride + c] = (float)best[j];
-#ifdef SRH_DIAG_G1      // diagnostic build: the front candidate and its depth lower bound
-      if (nearest) nearest[row * F.near_stride + c] = Q.g1[j];
-      depth[row * F.depth_stride + c] = Q.lo1[j];
-#elif defined(SRH_DIAG_AGAIN)   // diagnostic build: why did this pixel ask for a re-sweep (0 = it did not)
-      if (nearest) nearest[row * F.near_stride + c] = !Q.again[j] ? 0 : (Q.bound[j] == __builtin_inff() ? 1 : 2);
+      depth[row * F.depth_stride + (c0 + j)] = (float)best;
+#ifdef SRH_DIAG_AGAIN   // diagnostic build: did this pixel take the slow path (1 = nothing confirmed yet, 2 = third bound)
+      if (nearest) nearest[row * F.near_stride + (c0 + j)] = !slow ? 0 : (bound == __builtin_inff() ? 1 : 2);
 #else
-      if (nearest) nearest[row * F.near_stride + c] = besti[j];
+      if (nearest) nearest[row * F.near_stride + (c0 + j)] = besti;
 #endif
     }
   }

@@ -18,16 +18,14 @@
 //                  (A = 0: "always a candidate" -- the disc's image is not an ellipse, etc.)
 //                  elongated ellipses use [2] ex [3] ey [4] iu [11] iv > 0: candidate iff
 //                  (u*iu)^2 + (v*iv)^2 - 1 <= 0,  u = ex*dc + ey*dr, v = ex*dr - ey*dc
-//                  [5..7] v0 v1 v2 [8] k [9] E [10] Esolid : depth estimate, see below
+//                  [5..7] w0 w1 w2 [8] kk [9] lo_den [10] hi_den : depth estimate, see plane_estimate_record
 //   sphere (12)    [0..4] as the disc, rest unused
 //   triangle (16)  {a_i, b_i, g_i} at [4i..4i+2], i < 3: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
-//                  [3] v0 [7] v1 [11] v2 [12] k [13] E [14] Esolid
-//   plane (8)      [0..2] v0 v1 v2 [3] k [4] E [5] Esolid; every pixel is a candidate
+//                  [3] w0 [7] w1 [11] w2 [12] kk [13] lo_den [14] hi_den
+//   plane (8)      [0..2] w0 w1 w2 [3] kk [4] lo_den [5] hi_den; every pixel is a candidate
 //
 // Depth estimate of a planar primitive (disc, triangle, plane): the ray distance is
-//   t = k |D| / (n^.D),   n^.D = v0 + c*v1 + r*v2   with v_j = n^.{D0, Dc, Dr}
-// E bounds the absolute fp32 error of the evaluated denominator; Esolid = 1024 E is the smallest |denominator|
-// for which the estimate is trusted.
+//   t = k |D| / (n^.D),   n^.D = v0 + c*v1 + r*v2   with v_j = n^.{D0, Dc, Dr}   (affine in the pixel coordinates)
 #pragma once
 #include "srh_device.h"
 
@@ -53,16 +51,31 @@ __device__ inline void rec_zero(float* out, int n) {
   for (int i = 0; i < n; ++i) out[i] = 0.0f;
 }
 
-// v0, v1, v2, k, E, Esolid of a planar primitive with unit normal n and plane offset k
+// Depth-estimate fields of a planar primitive with unit normal n and plane offset k (see the file header):
+//   w0 = s v0 + E, w1 = s v1, w2 = s v2 with s = sign(k), kk = |k| (1 - 2^-20), lo_den, hi_den.
+// The kernel evaluates den = w0 + c w1 + r w2 = s (n^.D) + E up to an fp32 error below E, where
+//   E = 2^-21 (|v0| + W |v1| + H |v2|)  covers the three rounded coefficients and the two fmas (2.7x slack),
+// so 0 < s (n^.D) <= den whenever den >= lo_den = 1025 E, and then  t = |k| |D| / (s n^.D) >= kk |D| / den
+// (the 2^-20 absorbs the roundings of kk, |D|, the reciprocal and the two products).
+//   den >= lo_den          trusted: lower bound = kk |D| rcp(den); the sign is right, so t > 0
+//   hi_den < den < lo_den  grazing: no usable bound, the pair must be confirmed
+//   den <= hi_den = -1023 E   provably t < 0: never a valid hit when near > 0
 __device__ inline void plane_estimate_record(const double n[3], double k, const PixelBasis& B, int W, int H,
-                                             float* v0, float* v1, float* v2, float* kk, float* E, float* Es) {
+                                             float* w0, float* w1, float* w2, float* kk, float* lo_den,
+                                             float* hi_den) {
   const double a = dot3(n, B.D0), b = dot3(n, B.Dc), c = dot3(n, B.Dr);
-  // 2^-21 (|v0| + W|v1| + H|v2|): the three fp32-rounded coefficients and the two fmas, with 2x slack
+  const double sg = (k > 0.0) ? 1.0 : ((k < 0.0) ? -1.0 : 0.0);
   double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H);
-  if (!isfinite(e) || !isfinite(k) || !(e < 1.0e30)) e = 1.0e30;   // never "solid": candidates get confirmed
-  *v0 = (float)a; *v1 = (float)b; *v2 = (float)c; *kk = (float)k;
-  *E = (float)e * 1.0000002f;
-  *Es = (float)(1024.0 * e) * 1.0000002f;
+  if (!isfinite(e) || !isfinite(k) || !(e < 1.0e30) || !(fabs(k) < 1.0e30)) {
+    *w0 = *w1 = *w2 = *kk = 0.0f;      // den = 0 everywhere: always "grazing", every candidate is confirmed
+    *lo_den = 1.0f;
+    *hi_den = -1.0f;
+    return;
+  }
+  *w0 = (float)(sg * a + e); *w1 = (float)(sg * b); *w2 = (float)(sg * c);
+  *kk = (float)(fabs(k) * (1.0 - 9.5367431640625e-7));
+  *lo_den = (float)(1025.0 * e) * 1.0000002f;
+  *hi_den = (float)(-1023.0 * e) * 1.0000002f;
 }
 
 // Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4], out[11].
@@ -154,11 +167,15 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
   auto Ts = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
   const double s_sphere = conic_record(Ts(0, 0), Ts(0, 1), Ts(0, 2), Ts(1, 1), Ts(1, 2), Ts(2, 2), W, H, sph);
   const double s_disc = conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
-  if (s_sphere > 0.0 && (s_disc < 0.0 || s_disc > 1.5 * s_sphere + 2.0)) {
+  const bool degenerate = s_disc < 0.0 || (s_sphere > 0.0 && s_disc > 1.5 * s_sphere + 2.0);
+  if (degenerate && s_sphere > 0.0) {
     for (int i = 0; i < 5; ++i) out[i] = sph[i];
     out[11] = sph[11];
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
+  // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
+  // withdraw the estimate (every den counts as grazing) so such candidates are confirmed instead of ranked.
+  if (degenerate) { out[9] = 3.0e38f; out[10] = -3.0e38f; }
 }
 
 // sphere: the ray's line meets it iff (oc.D)^2 - |D|^2 (|oc|^2 - r^2) >= 0   (numpy/renderer.py:20-25).
@@ -212,13 +229,15 @@ __device__ inline void plane_reject_record(const double* R, const PixelBasis& B,
   plane_estimate_record(R, R[3], B, W, H, out + 0, out + 1, out + 2, out + 3, out + 4, out + 5);
 }
 
-// fp32 evaluation of the ellipse record for four pixels of one row: value <= 0 means "candidate".
-__device__ __forceinline__ void ellipse_reject4(const float* __restrict__ R, const float cf[4], float rf, float q[4]) {
+// fp32 evaluation of the ellipse record for N pixels of one row: value <= 0 means "candidate".
+template <int N>
+__device__ __forceinline__ void ellipse_reject(const float* __restrict__ R, const float (&cf)[N], float rf,
+                                               float (&q)[N]) {
   const float dr = rf - R[1];
   if (R[11] > 0.0f) {                                     // principal-axes form (wave-uniform branch)
     const float eydr = R[3] * dr, exdr = R[2] * dr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < N; ++j) {
       const float dc = cf[j] - R[0];
       const float u = __builtin_fmaf(R[2], dc, eydr) * R[4];
       const float v = __builtin_fmaf(-R[3], dc, exdr) * R[11];
@@ -228,7 +247,7 @@ __device__ __forceinline__ void ellipse_reject4(const float* __restrict__ R, con
     const float ee = R[3] * dr;
     const float gg = __builtin_fmaf(R[4] * dr, dr, -1.0f);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < N; ++j) {
       const float dc = cf[j] - R[0];
       q[j] = __builtin_fmaf(dc, __builtin_fmaf(R[2], dc, ee), gg);
     }
