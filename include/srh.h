@@ -134,6 +134,33 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                    void* workspace, size_t workspace_bytes,
                    float* image, float* depth, int32_t* nearest, void* stream);
 
+/* Gradient accumulators (device pointers; NULL = gradient not wanted).  srh_render_bwd ADDS into them with fp32
+ * atomics, so the caller zero-fills them first; sums over many pixels are therefore reproducible only to
+ * rounding.  Layouts equal the corresponding inputs. */
+typedef struct SrhGrads {
+  float* pos[SRH_MAX_SEGMENTS];      /* (count,4)   disk, plane, sphere; w gets no gradient */
+  float* normal[SRH_MAX_SEGMENTS];   /* (count,4)   disk, plane, triangle (the un-normalised input normal) */
+  float* radius[SRH_MAX_SEGMENTS];   /* (count)     sphere; a disc's radius has no gradient (masks are piecewise constant) */
+  float* face[SRH_MAX_SEGMENTS];     /* (count,3,4) triangle: only vertex 0, the plane point, is differentiated */
+  float* lights_pos;                 /* (n_lights,4) */
+  float* colors;                     /* (n_colors,3) */
+  float* albedo;                     /* (n_materials,3) */
+} SrhGrads;
+
+/* Analytic backward of srh_render_fwd: the vector-Jacobian product of (image, depth) w.r.t. the scene arrays for the
+ * upstream gradients grad_image (rows,W,3) and grad_depth (rows,W; may be NULL), using the winners saved by the
+ * forward pass (`nearest`, and `depth` to tell hit pixels from background).  Defined exactly as autograd through
+ * the reference's differentiable backend defines it (diffrend/torch/renderer.py:136-355, torch/utils.py:238-366):
+ * the nearest-hit selection and all masks are piecewise constant, so gradients flow only through the winner's hit
+ * distance, hit point, normal, albedo and the lights.  Row strides and the row range come from `params` as in the
+ * forward call. */
+int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                   const SrhMaterials* materials, const SrhParams* params,
+                   void* workspace, size_t workspace_bytes,
+                   const float* grad_image, const float* grad_depth,
+                   const int32_t* nearest, const float* depth,
+                   const SrhGrads* grads, void* stream);
+
 /* measurement helpers: timing-enabled HIP events usable as SrhParams.ev_start / ev_stop.
  * srh_event_elapsed_ms waits for `stop` to complete (the only call here that blocks the host). */
 int srh_event_create(void** event);

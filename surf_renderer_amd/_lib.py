@@ -53,7 +53,14 @@ class SrhParams(C.Structure):
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
+class SrhGrads(C.Structure):
+    _fields_ = [("pos", C.c_void_p * MAX_SEGMENTS), ("normal", C.c_void_p * MAX_SEGMENTS),
+                ("radius", C.c_void_p * MAX_SEGMENTS), ("face", C.c_void_p * MAX_SEGMENTS),
+                ("lights_pos", C.c_void_p), ("colors", C.c_void_p), ("albedo", C.c_void_p)]
+
+
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
+           "srh_render_bwd",
            "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
@@ -96,6 +103,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_render_fwd.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                    C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srh_render_bwd.restype = C.c_int
+    lib.srh_render_bwd.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
+                                   C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrhGrads), C.c_void_p]
     lib.srh_event_create.restype = C.c_int
     lib.srh_event_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.srh_event_destroy.restype = C.c_int

@@ -17,6 +17,7 @@
 #include "srh_device.h"
 #include "srh_reject.h"
 #include "srh_binned.h"
+#include "srh_backward.h"
 
 using namespace srh;
 
@@ -382,6 +383,65 @@ int check_rows(const FrameDev& F, int row0, int row1) {
   return SRH_OK;
 }
 
+// Validation and per-frame constants shared by the forward and the backward entry points.
+int setup_frame(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                FrameDev* Fp, WsLayout* Lp) {
+  FrameDev& F = *Fp;
+  memset(&F, 0, sizeof(F));
+  int rc = camera_to_frame(camera, &F);
+  if (rc) return rc;
+  if ((rc = check_objects(objects))) return rc;
+  if (!lights || !materials || !params) return fail(SRH_E_NULL, "lights / materials / params is NULL");
+  if ((rc = check_rows(F, params->row0, params->row1))) return rc;
+  if (lights->n_lights < 0 || lights->n_lights > SRH_MAX_LIGHTS)
+    return fail(SRH_E_RANGE, "n_lights = %d, expected 0..%d", lights->n_lights, SRH_MAX_LIGHTS);
+  if (lights->n_lights > 0 && (!lights->pos || !lights->color_idx || !lights->colors || lights->n_colors < 1))
+    return fail(SRH_E_NULL, "lights arrays missing");
+  if (materials->n_materials < 1 || !materials->albedo) return fail(SRH_E_NULL, "materials.albedo missing");
+  if (params->mode < SRH_MODE_AUTO || params->mode > SRH_MODE_BINNED) return fail(SRH_E_TYPE, "unknown mode %d", params->mode);
+  const WsLayout L = layout_for(objects, F.W, F.H);
+  *Lp = L;
+  if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % kAlign) != 0)
+    return fail(SRH_E_WORKSPACE, "workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", L.total,
+                workspace_bytes, workspace);
+  F.row0 = params->row0;
+  F.row1 = params->row1;
+  F.gamma = params->gamma;
+  F.tonemap = params->tonemap_gamma ? 1 : 0;
+  F.img_stride = params->image_row_stride ? params->image_row_stride : 3 * (int64_t)F.W;
+  F.depth_stride = params->depth_row_stride ? params->depth_row_stride : (int64_t)F.W;
+  F.near_stride = params->nearest_row_stride ? params->nearest_row_stride : (int64_t)F.W;
+  if (F.img_stride < 3 * (int64_t)F.W || F.depth_stride < F.W || F.near_stride < F.W)
+    return fail(SRH_E_RANGE, "output row strides shorter than a row");
+  F.nseg = objects->n_segments;
+  F.nlights = lights->n_lights;
+  F.ncolors = lights->n_colors;
+  F.nmat = materials->n_materials;
+  F.lpos = lights->pos;
+  F.lcidx = lights->color_idx;
+  F.colors = lights->colors;
+  F.albedo = materials->albedo;
+  int first = 0;
+  for (int s = 0; s < F.nseg; ++s) {
+    const SrhSegment& g = objects->seg[s];
+    SegDev& S = F.seg[s];
+    S.type = g.type;
+    S.count = g.count;
+    S.first = first;
+    S.rec64 = (const double*)((char*)workspace + L.off64[s]);
+    S.rec32 = (const float*)((char*)workspace + L.off32[s]);
+    S.pos = g.pos;
+    S.normal = g.normal;
+    S.radius = g.radius;
+    S.face = g.face;
+    S.mat = g.material_idx;
+    first += g.count;
+  }
+  F.total = first;
+  return SRH_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -422,59 +482,11 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                    const SrhMaterials* materials, const SrhParams* params, void* workspace,
                    size_t workspace_bytes, float* image, float* depth, int32_t* nearest, void* stream) {
   FrameDev F;
-  memset(&F, 0, sizeof(F));
-  int rc = camera_to_frame(camera, &F);
+  WsLayout L;
+  int rc = setup_frame(camera, objects, lights, materials, params, workspace, workspace_bytes, &F, &L);
   if (rc) return rc;
-  if ((rc = check_objects(objects))) return rc;
-  if (!lights || !materials || !params) return fail(SRH_E_NULL, "lights / materials / params is NULL");
-  if ((rc = check_rows(F, params->row0, params->row1))) return rc;
   if (!image || !depth) return fail(SRH_E_NULL, "image / depth is NULL");
-  if (lights->n_lights < 0 || lights->n_lights > SRH_MAX_LIGHTS)
-    return fail(SRH_E_RANGE, "n_lights = %d, expected 0..%d", lights->n_lights, SRH_MAX_LIGHTS);
-  if (lights->n_lights > 0 && (!lights->pos || !lights->color_idx || !lights->colors || lights->n_colors < 1))
-    return fail(SRH_E_NULL, "lights arrays missing");
-  if (materials->n_materials < 1 || !materials->albedo) return fail(SRH_E_NULL, "materials.albedo missing");
-  if (params->mode < SRH_MODE_AUTO || params->mode > SRH_MODE_BINNED) return fail(SRH_E_TYPE, "unknown mode %d", params->mode);
   const int mode = params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode;
-  const WsLayout L = layout_for(objects, F.W, F.H);
-  if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % kAlign) != 0)
-    return fail(SRH_E_WORKSPACE, "workspace: need %zu bytes, 256-byte aligned (got %zu at %p)", L.total,
-                workspace_bytes, workspace);
-
-  F.row0 = params->row0;
-  F.row1 = params->row1;
-  F.gamma = params->gamma;
-  F.tonemap = params->tonemap_gamma ? 1 : 0;
-  F.img_stride = params->image_row_stride ? params->image_row_stride : 3 * (int64_t)F.W;
-  F.depth_stride = params->depth_row_stride ? params->depth_row_stride : (int64_t)F.W;
-  F.near_stride = params->nearest_row_stride ? params->nearest_row_stride : (int64_t)F.W;
-  if (F.img_stride < 3 * (int64_t)F.W || F.depth_stride < F.W || F.near_stride < F.W)
-    return fail(SRH_E_RANGE, "output row strides shorter than a row");
-  F.nseg = objects->n_segments;
-  F.nlights = lights->n_lights;
-  F.ncolors = lights->n_colors;
-  F.nmat = materials->n_materials;
-  F.lpos = lights->pos;
-  F.lcidx = lights->color_idx;
-  F.colors = lights->colors;
-  F.albedo = materials->albedo;
-  int first = 0;
-  for (int s = 0; s < F.nseg; ++s) {
-    const SrhSegment& g = objects->seg[s];
-    SegDev& S = F.seg[s];
-    S.type = g.type;
-    S.count = g.count;
-    S.first = first;
-    S.rec64 = (const double*)((char*)workspace + L.off64[s]);
-    S.rec32 = (const float*)((char*)workspace + L.off32[s]);
-    S.pos = g.pos;
-    S.normal = g.normal;
-    S.radius = g.radius;
-    S.face = g.face;
-    S.mat = g.material_idx;
-    first += g.count;
-  }
-  F.total = first;
   hipStream_t st = (hipStream_t)stream;
   if (mode == SRH_MODE_BINNED) {
     F.tiles_x = L.tiles_x;
@@ -517,6 +529,38 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "render launch");
+}
+
+int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                   const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                   const float* grad_image, const float* grad_depth, const int32_t* nearest, const float* depth,
+                   const SrhGrads* grads, void* stream) {
+  FrameDev F;
+  WsLayout L;
+  int rc = setup_frame(camera, objects, lights, materials, params, workspace, workspace_bytes, &F, &L);
+  if (rc) return rc;
+  if (!grad_image || !nearest || !depth || !grads)
+    return fail(SRH_E_NULL, "grad_image / nearest / depth / grads is NULL");
+  GradsDev G;
+  for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) {
+    G.pos[s] = grads->pos[s]; G.normal[s] = grads->normal[s]; G.radius[s] = grads->radius[s]; G.face[s] = grads->face[s];
+  }
+  G.lights_pos = grads->lights_pos;
+  G.colors = grads->colors;
+  G.albedo = grads->albedo;
+  hipStream_t st = (hipStream_t)stream;
+  // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64,
+                       (float*)S.rec32);
+  }
+  const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+  if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
+  hipLaunchKernelGGL(k_render_bwd, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
+  if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "backward launch");
 }
 
 int srh_event_create(void** event) {

@@ -37,9 +37,11 @@ def _require_gpu(device: torch.device) -> None:
                            "there is no CPU fallback -- use the reference's numpy backend instead")
 
 
-def _as_tensor(x, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+def _as_tensor(x, dtype: torch.dtype, device: torch.device, keep_graph: bool = False) -> torch.Tensor:
+    """Contiguous device tensor of ``x``.  With ``keep_graph`` a tensor that requires grad stays attached to the
+    autograd graph (the casts and copies are differentiable), so gradients reach the caller's leaf."""
     if isinstance(x, torch.Tensor):
-        t = x.detach()
+        t = x if (keep_graph and x.requires_grad) else x.detach()
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
     return t.to(device=device, dtype=dtype).contiguous()
@@ -92,9 +94,10 @@ def _check_w(name: str, arr: Optional[np.ndarray], want: float) -> None:
                          f"docs/scene_description.md:3-5); found {np.unique(w)[:4]}")
 
 
-def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True) -> SceneBuffers:
+def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, keep_graph: bool = False) -> SceneBuffers:
     """Upload an expanded scene.  Object batches keep scene['objects'] dict order, which defines the
-    global primitive numbering (numpy/renderer.py:172-201).  The caller's scene is not modified."""
+    global primitive numbering (numpy/renderer.py:172-201).  The caller's scene is not modified.
+    ``keep_graph`` keeps tensors that require grad attached to autograd (see ``render``)."""
     device = torch.device(device)
     _require_gpu(device)
     lib = _lib.load()
@@ -117,7 +120,7 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True) -
         seg.type = PRIM_CODE[kind]
         count = None
         for name in _OBJ_FIELDS[kind]:
-            t = _as_tensor(grp[name], f32, device)
+            t = _as_tensor(grp[name], f32, device, keep_graph)
             if name == "radius":
                 t = t.reshape(-1)
             elif name == "face":
@@ -153,10 +156,10 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True) -
     ob.n_segments = len(kinds)
 
     lights = scene["lights"]
-    lpos = _as_tensor(lights["pos"], f32, device).reshape(-1, 4)
+    lpos = _as_tensor(lights["pos"], f32, device, keep_graph).reshape(-1, 4)
     lidx = _as_tensor(lights["color_idx"], i32, device).reshape(-1)
-    colors = _as_tensor(scene["colors"], f32, device).reshape(-1, 3)
-    albedo = _as_tensor(scene["materials"]["albedo"], f32, device).reshape(-1, 3)
+    colors = _as_tensor(scene["colors"], f32, device, keep_graph).reshape(-1, 3)
+    albedo = _as_tensor(scene["materials"]["albedo"], f32, device, keep_graph).reshape(-1, 3)
     if lpos.shape[0] != lidx.shape[0]:
         raise ValueError("lights.pos and lights.color_idx disagree on the number of lights")
     if lpos.shape[0] > _lib.MAX_LIGHTS:
@@ -289,6 +292,69 @@ def generate_rays(camera: Dict[str, Any], device="cuda", rows: Optional[Tuple[in
     return out
 
 
+def _float_keys(buf: SceneBuffers) -> List[str]:
+    """Keys of buf.tensors that are differentiable inputs, in a fixed order."""
+    keys = [f"{kind}.{name}" for kind in buf.kinds for name in _OBJ_FIELDS[kind]]
+    return keys + ["lights.pos", "colors", "materials.albedo"]
+
+
+class _RenderFunction(torch.autograd.Function):
+    """render_buffers with the analytic backward of libsrh (srh_render_bwd).  Gradient semantics are those of
+    autograd through the reference's torch backend (SURVEY.md section 8, row a-B): selection and masks are piecewise
+    constant; a disc's radius and a triangle's vertices 1, 2 receive zero gradient."""
+
+    @staticmethod
+    def forward(ctx, buf, cam, rows, mode, *inputs):
+        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode)
+        ctx.buf, ctx.cam, ctx.rows, ctx.mode = buf, cam, rows, mode
+        ctx.save_for_backward(depth, nearest)
+        ctx.mark_non_differentiable(nearest)
+        return image, depth, nearest
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, _g_nearest):
+        buf, cam = ctx.buf, ctx.cam
+        depth, nearest = ctx.saved_tensors
+        lib = _lib.load()
+        width, height = frame_size(cam)
+        r0, r1 = (0, height) if ctx.rows is None else (int(ctx.rows[0]), int(ctx.rows[1]))
+        keys = _float_keys(buf)
+        need = ctx.needs_input_grad[4:]
+        grads: Dict[str, torch.Tensor] = {}
+        sg = _lib.SrhGrads()
+        for key, want in zip(keys, need):
+            if not want:
+                continue
+            g = torch.zeros_like(buf.tensors[key])
+            grads[key] = g
+            if key == "lights.pos":
+                sg.lights_pos = g.data_ptr()
+            elif key == "colors":
+                sg.colors = g.data_ptr()
+            elif key == "materials.albedo":
+                sg.albedo = g.data_ptr()
+            else:
+                kind, name = key.split(".")
+                s = buf.kinds.index(kind)
+                if name == "radius" and kind == "disk":
+                    continue                      # identically zero (numpy/renderer.py:88: the radius only feeds a mask)
+                getattr(sg, name)[s] = g.data_ptr()
+        g_image = g_image.to(torch.float32).contiguous() if g_image is not None else \
+            torch.zeros((r1 - r0, width, 3), dtype=torch.float32, device=buf.device)
+        g_depth = g_depth.to(torch.float32).contiguous() if g_depth is not None else None
+        params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[ctx.mode],
+                                tonemap_gamma=0 if buf.gamma is None else 1,
+                                gamma=1.0 if buf.gamma is None else buf.gamma)
+        workspace = buf.ensure_workspace(width, height)
+        with torch.cuda.device(buf.device):
+            rc = lib.srh_render_bwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                    C.byref(params), workspace.data_ptr(), workspace.numel(),
+                                    g_image.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
+                                    nearest.data_ptr(), depth.data_ptr(), C.byref(sg), _stream_ptr(buf.device))
+        _lib.check(rc)
+        return (None, None, None, None) + tuple(grads.get(k) for k in keys)
+
+
 class RenderResult(dict):
     """The reference's result dict.  ``image`` (H,W,3), ``depth`` (H,W) and ``nearest`` (H,W) are always
     present; ``ray_dir`` (4,N) is produced on first access.  The three O(M*N) entries of the numpy
@@ -323,7 +389,13 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     if unknown:
         raise TypeError(f"render() got unexpected keyword arguments {sorted(unknown)}")
     device = torch.device(params.get("device", "cuda"))
-    buf = flatten_scene(scene, device, validate=params.get("validate", True))
+    buf = flatten_scene(scene, device, validate=params.get("validate", True), keep_graph=torch.is_grad_enabled())
     cam = camera_struct(scene["camera"])
-    image, depth, nearest = render_buffers(buf, cam, rows=params.get("rows"), mode=params.get("mode", "auto"))
+    rows, mode = params.get("rows"), params.get("mode", "auto")
+    inputs = [buf.tensors[k] for k in _float_keys(buf)]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
+        # differentiable call: image and depth carry a grad_fn backed by the analytic HIP backward
+        image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, *inputs)
+    else:
+        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode)
     return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64))
