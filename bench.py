@@ -7,7 +7,8 @@ configs[4]), framebuffer row-tiled over N MI355X with one RCCL gather per frame.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is one frame: every rank renders its row slab from primitive arrays already resident in HBM
-(prep kernel + render kernel), then the slabs are gathered on rank 0.  Rank 0 prints ONE JSON line.
+(prep, binning and render kernels), then the slabs are gathered on rank 0; with more than one rank the gather of
+a frame overlaps the render of the next one (two frames in flight).  Rank 0 prints ONE JSON line.
 ``value`` = frames/s of the whole job; tests/s = primitives x pixels x frames/s (algorithmic pairs, i.e.
 what the reference evaluates, whatever the kernel skips).  Total work is fixed as N grows -> "strong".
 """
@@ -35,12 +36,15 @@ FLOP_PER_DISK_TEST = 17        # SURVEY.md section 8d (arithmetic only, per-prim
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="auto", choices=["auto", "exact", "fast", "binned"])
     ap.add_argument("--prims", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="frames in flight: each has its own stream, scratch and output buffers, so the binning "
+                         "kernels of one frame overlap the render kernel of another")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
     return ap.parse_args()
@@ -78,6 +82,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    if os.environ.get("SRH_BENCH_SINGLE_DEVICE"):      # rehearsal on a one-GPU box: every rank shares device 0
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
@@ -93,23 +99,46 @@ def main():
     r0, r1 = row_slab(H, rank, world)
     h = r1 - r0
 
-    # one (rows, 4W) fp32 slab per rank: [W x rgb | W x depth] per row, so a single gather moves both
-    if rank == 0:
-        frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
-        slab = frame[r0:r1]
-    else:
-        frame = None
-        slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
-    image = slab.as_strided((h, W, 3), (4 * W, 3, 1), slab.storage_offset())
-    depth = slab.as_strided((h, W), (4 * W, 1), slab.storage_offset() + 3 * W)
+    # One (rows, 4W) fp32 slab per rank -- [W x rgb | W x depth] per row -- so a single gather moves both; rank 0
+    # renders straight into its rows of the full (H, 4W) frame.  Two frames are kept in flight: the gather of frame
+    # i (RCCL, its own stream) overlaps the render of frame i+1, and a buffer is reused only after its gather is done.
+    n_buf = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device) for _ in range(n_buf)]
+    scratch = [buf.new_workspace(W, H) for _ in range(n_buf)]
+    frames, slabs, images, depths = [], [], [], []
+    for _ in range(n_buf):
+        if rank == 0:
+            frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
+            slab = frame[r0:r1]
+        else:
+            frame = None
+            slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
+        frames.append(frame)
+        slabs.append(slab)
+        images.append(slab.as_strided((h, W, 3), (4 * W, 3, 1), slab.storage_offset()))
+        depths.append(slab.as_strided((h, W), (4 * W, 1), slab.storage_offset() + 3 * W))
     events = [_lib.EventPair() for _ in range(args.steps)]
+    pending = [None] * n_buf
+    counter = [0]
 
     def step(ev=None):
-        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None), events=ev)
-        if world > 1:
-            gather_rows(slab, frame, H, dst=0)
+        b = counter[0] % n_buf
+        counter[0] += 1
+        if pending[b] is not None:
+            with torch.cuda.stream(streams[b]):
+                pending[b].wait()                  # this buffer's previous frame has left
+            pending[b] = None
+        with torch.cuda.stream(streams[b]):
+            renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(images[b], depths[b], None),
+                                    events=ev, workspace=scratch[b])
+            if world > 1:
+                pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
 
     def fence():
+        for b in range(n_buf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -152,6 +181,7 @@ def main():
             "config": {"workload": "BASELINE configs[4]: 100k synthetic disk splats, 2048x2048, forward render, "
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
+                       "frames_in_flight": n_buf,
                        "parallelism": f"rows/{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,

@@ -80,7 +80,7 @@ __device__ inline void plane_estimate_record(const double n[3], double k, const 
 
 // Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4], out[11].
 // Returns the major semi-axis in pixels, or -1 (record = "always a candidate") when the conic is not a
-// well-conditioned ellipse: not positive definite, centre or size beyond 2^20 pixels, or axis ratio > 4096
+// well-conditioned ellipse: not positive definite, centre or size beyond 2^20 pixels, or axis ratio > 512
 // (a disc seen edge-on; its parameters are then numerical noise).
 __device__ inline double conic_record(double T00, double T01, double T02, double T11, double T12, double T22,
                                       int W, int H, float* out) {
@@ -100,7 +100,7 @@ __device__ inline double conic_record(double T00, double T01, double T02, double
   const double smax = 1.0 / sqrt(lmin);
   const double far_lim = 1048576.0;
   if (!(fabs(c0) < far_lim) || !(fabs(r0) < far_lim) || !(smax < far_lim)) return -1.0;
-  if (!(smax <= 4096.0 * smin)) return -1.0;
+  if (!(smax <= 512.0 * smin)) return -1.0;
   double cond = (smax / smin) * (smax / smin);   // terms of the quadratic form reach cond * Q near the boundary
   const double pos_err = 2.384185791015625e-7 * (fabs(c0) + fabs(r0) + W + H);   // 2^-22 (...), see below
   if (smax > 8.0 * smin) {
@@ -157,20 +157,16 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
     for (int a = 0; a < 3; ++a) u[j][a] = oc[a] * nu[j] + k * P[j][a];
   }
   auto T = [&](int i, int j) { return dot3(u[i], u[j]) - r2 * nu[i] * nu[j]; };
-  // Every hit lies on the disc, hence inside the sphere around its centre with its radius.  That sphere's
-  // silhouette is a robust, well-conditioned ellipse: it replaces the disc's own image when that is degenerate
-  // (seen edge-on) and it caps the disc ellipse's size, which must fit inside it.
-  float sph[12];
-  const double cq = dot3(oc, oc) - r2;
-  double w[3];
-  for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
-  auto Ts = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
-  const double s_sphere = conic_record(Ts(0, 0), Ts(0, 1), Ts(0, 2), Ts(1, 1), Ts(1, 2), Ts(2, 2), W, H, sph);
-  const double s_disc = conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
-  const bool degenerate = s_disc < 0.0 || (s_sphere > 0.0 && s_disc > 1.5 * s_sphere + 2.0);
-  if (degenerate && s_sphere > 0.0) {
-    for (int i = 0; i < 5; ++i) out[i] = sph[i];
-    out[11] = sph[11];
+  const bool degenerate = conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out) < 0.0;
+  if (degenerate) {
+    // The disc's own image is not a usable ellipse (seen edge-on: axis ratio beyond 512, parameters are noise).
+    // Every hit lies on the disc, hence inside the sphere around its centre with its radius, and that sphere's
+    // silhouette is a robust, well-conditioned ellipse.  Rare (|cos| < 2e-3), so the extra work is off the common path.
+    const double cq = dot3(oc, oc) - r2;
+    double w[3];
+    for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
+    auto Ts = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
+    (void)conic_record(Ts(0, 0), Ts(0, 1), Ts(0, 2), Ts(1, 1), Ts(1, 2), Ts(2, 2), W, H, out);
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:

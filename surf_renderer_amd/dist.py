@@ -27,26 +27,41 @@ def all_slabs(height: int, world: int) -> List[Tuple[int, int]]:
     return [row_slab(height, g, world) for g in range(world)]
 
 
+class GatherHandle:
+    """Completion handle of one frame's gather (possibly several point-to-point requests)."""
+
+    def __init__(self, works=()):
+        self._works = [w for w in works if w is not None]
+
+    def wait(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
 def gather_rows(slab: torch.Tensor, full: Optional[torch.Tensor], height: int, dst: int = 0,
-                group: Optional[dist.ProcessGroup] = None) -> None:
+                group: Optional[dist.ProcessGroup] = None, async_op: bool = False) -> GatherHandle:
     """Collect per-rank row slabs ``slab`` ((h_g, W, ...) contiguous) into ``full`` ((H, W, ...), only
     needed on ``dst``).  Equal slabs use one ``gather`` whose receive list are views of ``full`` (no
-    staging copy); ragged slabs fall back to one batched send/recv group."""
+    staging copy); ragged slabs fall back to one batched send/recv group.  With ``async_op`` the call
+    returns at once and the handle's ``wait()`` orders later work on the current stream after the transfer,
+    which lets the next frame's render overlap this frame's gather."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     slabs = all_slabs(height, world)
     if world == 1:
         if full is not None and full.data_ptr() != slab.data_ptr():
             full.copy_(slab)
-        return
+        return GatherHandle()
     equal = len({r1 - r0 for r0, r1 in slabs}) == 1
+    views = None
     if rank == dst:
         if full is None or full.shape[0] != height:
             raise ValueError("the destination rank must pass the full (H, W, ...) buffer")
         views = [full[r0:r1] for r0, r1 in slabs]
     if equal:
-        dist.gather(slab, gather_list=views if rank == dst else None, dst=dst, group=group)
-        return
+        work = dist.gather(slab, gather_list=views, dst=dst, group=group, async_op=async_op)
+        return GatherHandle([work] if async_op else [])
     ops = []
     if rank == dst:
         r0, r1 = slabs[dst]
@@ -57,6 +72,7 @@ def gather_rows(slab: torch.Tensor, full: Optional[torch.Tensor], height: int, d
                 ops.append(dist.P2POp(dist.irecv, views[g], g, group))
     elif slab.shape[0] > 0:
         ops.append(dist.P2POp(dist.isend, slab, dst, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    handle = GatherHandle(dist.batch_isend_irecv(ops) if ops else [])
+    if not async_op:
+        handle.wait()
+    return handle

@@ -81,6 +81,14 @@ class SceneBuffers:
             self.workspace_frame = (w, h)
         return self.workspace
 
+    def new_workspace(self, width: int, height: int) -> torch.Tensor:
+        """An additional scratch buffer (one per frame in flight when frames are pipelined over several streams)."""
+        lib = _lib.load()
+        need = lib.srh_workspace_bytes(C.byref(self.objects), width, height)
+        if need == 0:
+            raise _lib.SrhError(-1, lib.srh_last_error().decode())
+        return torch.empty(need, dtype=torch.uint8, device=self.device)
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors.values())
 
@@ -238,10 +246,12 @@ def _stream_ptr(device: torch.device) -> int:
 
 def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                    mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
-                   want_nearest: bool = True, events: Optional[_lib.EventPair] = None):
+                   want_nearest: bool = True, events: Optional[_lib.EventPair] = None,
+                   workspace: Optional[torch.Tensor] = None):
     """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
     enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
-    preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None)."""
+    preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None).  ``workspace`` overrides the
+    buffers' own scratch: frames in flight on different streams each need their own (``new_workspace``)."""
     lib = _lib.load()
     width, height = frame_size(cam)
     r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
@@ -267,7 +277,8 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                             depth_row_stride=depth.stride(0) if h > 1 else 0,
                             nearest_row_stride=nearest.stride(0) if (nearest is not None and h > 1) else 0,
                             ev_start=events.start if events else None, ev_stop=events.stop if events else None)
-    workspace = buf.ensure_workspace(width, height)
+    if workspace is None:
+        workspace = buf.ensure_workspace(width, height)
     with torch.cuda.device(buf.device):
         rc = lib.srh_render_fwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                 C.byref(params), workspace.data_ptr(), workspace.numel(),

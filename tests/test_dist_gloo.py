@@ -57,7 +57,7 @@ def _worker(rank, world, port, height, width, q):
         depth = slab.as_strided((r1 - r0, width), (4 * width, 1), slab.storage_offset() + 3 * width)
         image.copy_(torch.from_numpy(part["image"].astype(np.float32)))
         depth.copy_(torch.from_numpy(part["depth"].astype(np.float32)))
-        gather_rows(slab, frame, height, dst=0)
+        gather_rows(slab, frame, height, dst=0, async_op=(height % 2 == 0)).wait()
         if rank == 0:
             full = np_oracle.render(scene)
             fb = frame.numpy()
