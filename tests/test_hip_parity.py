@@ -193,3 +193,17 @@ def test_config5_full_size_modes_identical_and_row_slabs():
     for k in range(3):
         np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), ref[k])
     _oracle_rows_check(scene, {"image": a[0], "depth": a[1], "nearest": a[2].astype(np.int64)}, [(1024, 1025)])
+
+
+def test_long_tile_lists_saturate_the_ordinal():
+    """More than 4095 primitives in one tile: the packed keys' ordinal saturates and such pixels must resolve on
+    the wave-parallel slow path -- still bit-identical to the all-pairs mode."""
+    from surf_renderer_amd import synthetic
+    scene = synthetic.disk_cloud_scene(30000, 48, 32, radius=0.05, seed=17)
+    ref = _modes_identical(scene, modes=("exact", "binned"))
+    assert np.isfinite(ref["depth"]).mean() > 0.3
+    # many large primitives (every one lands in the frame-wide list) plus near <= 0 (no depth pre-test at all)
+    scene = synthetic.disk_cloud_scene(300, 96, 64, radius=0.9, seed=18)
+    _modes_identical(scene, modes=("exact", "binned"))
+    scene["camera"]["near"] = 0.0
+    _modes_identical(scene, modes=("exact", "binned"))

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Secondary measurements: BASELINE configs 1-4 (forward frames/s, and forward+backward for config 4) on one GPU.
+Prints one JSON line per config.  Not the headline benchmark (that is bench.py = config 5)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+from surf_renderer_amd import renderer, synthetic
+
+
+def timed(fn, steps=50, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def forward_rate(name, scene, steps=50):
+    buf = renderer.flatten_scene(scene, "cuda:0")
+    cam = renderer.camera_struct(scene["camera"])
+    w, h = renderer.frame_size(cam)
+    out = (torch.empty((h, w, 3), device="cuda:0"), torch.empty((h, w), device="cuda:0"),
+           torch.empty((h, w), dtype=torch.int32, device="cuda:0"))
+    dt = timed(lambda: renderer.render_buffers(buf, cam, out=out), steps)
+    print(json.dumps({"config": name, "width": w, "height": h, "prims": buf.total, "ms_per_frame": 1e3 * dt,
+                      "frames_per_s": 1 / dt, "gtests_per_s": buf.total * w * h / dt / 1e9}), flush=True)
+
+
+def main():
+    forward_rate("1: scenes/basic.json 128x128", synthetic.json_scene("basic.json", 128, 128))
+    forward_rate("2: bunny.splat discs 512x512", synthetic.bunny_splat_scene(512, 512))
+    forward_rate("3a: halfbox_sphere_cube.json 1024x1024", synthetic.json_scene("halfbox_sphere_cube.json", 1024, 1024))
+    forward_rate("3b: mixed plane/sphere/disc/triangle, 4 lights, 1024x1024", synthetic.demo_scene(1024, 1024, with_planes=True))
+    mesh = synthetic.bunny_mesh_scene(1024, 1024)
+    forward_rate("4: bunny.obj triangles 1024x1024 (forward)", mesh)
+    # forward + analytic backward through render(): d image / d vertex 0, d image / d normal
+    tri = mesh["objects"]["triangle"]
+    face = torch.tensor(np.asarray(tri["face"], dtype=np.float32), device="cuda:0", requires_grad=True)
+    normal = torch.tensor(np.asarray(tri["normal"], dtype=np.float32), device="cuda:0", requires_grad=True)
+    mesh["objects"]["triangle"] = {"face": face, "normal": normal,
+                                   "material_idx": torch.tensor(np.asarray(tri["material_idx"]), device="cuda:0")}
+    for key in ("pos",):
+        mesh["lights"][key] = torch.tensor(np.asarray(mesh["lights"][key], dtype=np.float32), device="cuda:0")
+    mesh["colors"] = torch.tensor(np.asarray(mesh["colors"], dtype=np.float32), device="cuda:0")
+    mesh["materials"]["albedo"] = torch.tensor(np.asarray(mesh["materials"]["albedo"], dtype=np.float32), device="cuda:0")
+
+    def fwd_bwd():
+        face.grad = None
+        normal.grad = None
+        res = renderer.render(mesh, device="cuda:0", validate=False)
+        res["image"].sum().backward()
+
+    dt = timed(fwd_bwd, steps=20, warmup=3)
+    print(json.dumps({"config": "4: bunny.obj 1024x1024 forward + backward through render() (Python flatten included)",
+                      "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
