@@ -91,13 +91,25 @@ typedef struct SrhLights {
   const float* pos;             /* (n_lights,4) device */
   const int32_t* color_idx;     /* (n_lights)   device, rows of `colors` */
   const float* colors;          /* (n_colors,3) device */
+  const float* attenuation;     /* (n_lights,3) device, (kc, kl, kq); SRH_SHADING_TORCH only, NULL = (1,0,0) */
+  const float* ambient;         /* (3) device; SRH_SHADING_TORCH only, NULL = 0 */
 } SrhLights;
 
 /* scene['materials'] (numpy/renderer.py:245) */
 typedef struct SrhMaterials {
   int32_t n_materials;
   const float* albedo;          /* (n_materials,3) device */
+  const float* coeffs;          /* (n_materials,3) device, (diffuse, specular, shininess); SRH_SHADING_TORCH only,
+                                   NULL = (1,0,0) */
 } SrhMaterials;
+
+/* Which of the reference's two differentiable-renderer semantics a frame follows (SrhParams.shading). */
+enum {
+  SRH_SHADING_NUMPY = 0,  /* diffrend/numpy/renderer.py: Lambert, clip after the light sum, +inf background, the
+                             reference's non-orthonormal camera basis and 4-D normalisation */
+  SRH_SHADING_TORCH = 1   /* diffrend/torch/renderer.py:82-125,136-355: attenuation, per-light relu, specular, ambient,
+                             double_sided, use_quartic, orthonormal camera basis, far+1 background */
+};
 
 typedef struct SrhParams {
   int32_t row0, row1;           /* render image rows [row0,row1) of the camera's H rows; the output
@@ -105,6 +117,12 @@ typedef struct SrhParams {
   int32_t mode;                 /* SRH_MODE_* */
   int32_t tonemap_gamma;        /* 1: image <- image ** gamma  (scene has a 'tonemap' entry, :262) */
   double gamma;
+  int32_t shading;              /* SRH_SHADING_* */
+  int32_t double_sided;         /* torch shading: flip the normal towards the viewer (torch/renderer.py:107-112) */
+  int32_t use_quartic;          /* torch shading: attenuation uses d^4 instead of d^2 (torch/renderer.py:92) */
+  int32_t reserved0;
+  float* normal_out;            /* optional (rows,W,3) dense: unit normal of the hit, 0 where nothing is hit */
+  float* pos_out;               /* optional (rows,W,3) dense: hit point, 0 where nothing is hit */
   int64_t image_row_stride;     /* elements between consecutive output rows; 0 = dense (3*W, W, W). */
   int64_t depth_row_stride;     /* Lets image and depth rows interleave in one (rows, 4*W) slab so that a */
   int64_t nearest_row_stride;   /* multi-GPU frame is collected by a single gather. */

@@ -30,6 +30,13 @@ def pack_scene(scene: Dict[str, Any]) -> Dict[str, np.ndarray]:
     flat["scene/lights/color_idx"] = np.asarray(scene["lights"]["color_idx"], dtype=np.int64)
     flat["scene/colors"] = np.asarray(scene["colors"], dtype=np.float32)
     flat["scene/materials/albedo"] = np.asarray(scene["materials"]["albedo"], dtype=np.float32)
+    # optional inputs of the torch backend's shading model
+    if "attenuation" in scene["lights"]:
+        flat["scene/lights/attenuation"] = np.asarray(scene["lights"]["attenuation"], dtype=np.float32)
+    if "ambient" in scene["lights"]:
+        flat["scene/lights/ambient"] = np.asarray(scene["lights"]["ambient"], dtype=np.float32)
+    if "coeffs" in scene["materials"]:
+        flat["scene/materials/coeffs"] = np.asarray(scene["materials"]["coeffs"], dtype=np.float32)
     for kind, grp in scene["objects"].items():
         for name, val in grp.items():
             dt = np.int64 if name == "material_idx" else np.float32
@@ -62,6 +69,10 @@ def unpack_scene(npz) -> Dict[str, Any]:
         "materials": {"albedo": npz["scene/materials/albedo"].astype(np.float64)},
         "objects": {},
     }
+    for key, (a, b) in {"scene/lights/attenuation": ("lights", "attenuation"), "scene/lights/ambient": ("lights", "ambient"),
+                        "scene/materials/coeffs": ("materials", "coeffs")}.items():
+        if key in npz.files:
+            scene[a][b] = npz[key].astype(np.float64)
     for kind in meta["objects_order"]:
         grp = {}
         prefix = f"scene/objects/{kind}/"

@@ -14,6 +14,7 @@ MAX_LIGHTS = 64
 
 MODE_AUTO, MODE_EXACT, MODE_FAST, MODE_BINNED = 0, 1, 2, 3
 MODES = {"auto": MODE_AUTO, "exact": MODE_EXACT, "fast": MODE_FAST, "binned": MODE_BINNED}
+SHADING = {"numpy": 0, "torch": 1}
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -38,16 +39,19 @@ class SrhObjects(C.Structure):
 
 class SrhLights(C.Structure):
     _fields_ = [("n_lights", C.c_int32), ("n_colors", C.c_int32),
-                ("pos", C.c_void_p), ("color_idx", C.c_void_p), ("colors", C.c_void_p)]
+                ("pos", C.c_void_p), ("color_idx", C.c_void_p), ("colors", C.c_void_p),
+                ("attenuation", C.c_void_p), ("ambient", C.c_void_p)]
 
 
 class SrhMaterials(C.Structure):
-    _fields_ = [("n_materials", C.c_int32), ("albedo", C.c_void_p)]
+    _fields_ = [("n_materials", C.c_int32), ("albedo", C.c_void_p), ("coeffs", C.c_void_p)]
 
 
 class SrhParams(C.Structure):
     _fields_ = [("row0", C.c_int32), ("row1", C.c_int32), ("mode", C.c_int32),
                 ("tonemap_gamma", C.c_int32), ("gamma", C.c_double),
+                ("shading", C.c_int32), ("double_sided", C.c_int32), ("use_quartic", C.c_int32), ("reserved0", C.c_int32),
+                ("normal_out", C.c_void_p), ("pos_out", C.c_void_p),
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]

@@ -44,14 +44,14 @@ size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 // ------------------------------------------------------------------------------------------------
 // k_prep: per-frame primitive records
 // ------------------------------------------------------------------------------------------------
-__device__ void prep_record64(const SegDev& S, int i, const double o[3], double* R);
+__device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R);
 
 __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
   double* R = rec64 + (size_t)i * kRec64Stride[S.type];
-  prep_record64(S, i, F.o, R);
+  prep_record64(S, i, F.o, F.shading != 0, R);
   // screen-space reject record of the FAST / binned modes, from the fp64 record just written
   float* Q = rec32 + (size_t)i * kRec32Stride[S.type];
   const PixelBasis B = pixel_basis(F);
@@ -65,14 +65,15 @@ __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, 
   if (F.tilerange) bin_primitive(F, s, S.type, Q, S.first + i);
 }
 
-__device__ void prep_record64(const SegDev& S, int i, const double o[3], double* R) {
-
+__device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R) {
   double nh[3] = {0, 0, 0};
   if (S.type != SRH_PRIM_SPHERE) {
     // ops.normalize: divide by the 4-D length, by 1 if that is zero (numpy/ops.py:18-26)
     const float* q = S.normal + 4 * (size_t)i;
     const double v[4] = {(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
     double len = sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    // the torch backend normalises xyz only, with an eps inside the sum (torch/utils.py:131-135, :289)
+    if (tch) len = sqrt(((v[0] * v[0] + 1e-10) + (v[1] * v[1] + 1e-10)) + (v[2] * v[2] + 1e-10));
     if (!(fabs(len) > 0.0)) len = 1.0;
     nh[0] = v[0] / len; nh[1] = v[1] / len; nh[2] = v[2] / len;
   }
@@ -133,14 +134,15 @@ __global__ __launch_bounds__(256) void k_rays(FrameDev F, float* ray_dir) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_pixel(const FrameDev& F, int c, int r, const float rgb[3], double z, int win,
                                             float* __restrict__ image, float* __restrict__ depth,
-                                            int32_t* __restrict__ nearest) {
+                                            int32_t* __restrict__ nearest, const float* aux = nullptr) {
   const size_t row = (size_t)(r - F.row0);
   float* px = image + row * F.img_stride + 3 * (size_t)c;
   px[0] = rgb[0];
   px[1] = rgb[1];
   px[2] = rgb[2];
-  depth[row * F.depth_stride + c] = (float)z;
+  depth[row * F.depth_stride + c] = background_depth(F, z);
   if (nearest) nearest[row * F.near_stride + c] = win;
+  if (aux) store_aux(F, row, c, aux);
 }
 
 __global__ __launch_bounds__(256) void k_render_exact(FrameDev F, float* __restrict__ image,
@@ -157,13 +159,14 @@ __global__ __launch_bounds__(256) void k_render_exact(FrameDev F, float* __restr
     const SegDev& S = F.seg[s];
     const int stride = kRec64Stride[S.type];
     for (int i = 0; i < S.count; ++i) {
-      const double t = hit_any64(S.type, S.rec64 + (size_t)i * stride, F.o, d);
+      const double t = hit_any64(S.type, S.rec64 + (size_t)i * stride, F.o, d, F.shading != 0);
       resolve(F, t, S.first + i, best, besti);
     }
   }
-  float rgb[3];
-  shade_pixel(F, d, best, besti, rgb);
-  if (live) store_pixel(F, c, r, rgb, best, besti, image, depth, nearest);
+  float rgb[3], aux[6];
+  const bool want_aux = F.normal_out || F.pos_out;
+  shade_pixel(F, d, best, besti, rgb, want_aux ? aux : nullptr);
+  if (live) store_pixel(F, c, r, rgb, best, besti, image, depth, nearest, want_aux ? aux : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,7 +187,7 @@ __device__ __forceinline__ void confirm(const FrameDev& F, const SegDev& S, int 
     if (cand && c < F.W) {
       double d[3];
       pixel_ray(F, c, r, d);
-      resolve(F, hit_any64(S.type, R, F.o, d), S.first + i, best[j], besti[j]);
+      resolve(F, hit_any64(S.type, R, F.o, d, F.shading != 0), S.first + i, best[j], besti[j]);
     }
   }
 }
@@ -269,9 +272,10 @@ __global__ __launch_bounds__(256) void k_render_fast(FrameDev F, float* __restri
     if (c < F.W) {      // wave-divergent only in the last column block
       double d[3];
       pixel_ray(F, c, r, d);
-      float rgb[3];
-      shade_pixel(F, d, best[j], besti[j], rgb);
-      if (row_live) store_pixel(F, c, r_raw, rgb, best[j], besti[j], image, depth, nearest);
+      float rgb[3], aux[6];
+      const bool want_aux = F.normal_out || F.pos_out;
+      shade_pixel(F, d, best[j], besti[j], rgb, want_aux ? aux : nullptr);
+      if (row_live) store_pixel(F, c, r_raw, rgb, best[j], besti[j], image, depth, nearest, want_aux ? aux : nullptr);
     }
   }
 }
@@ -348,7 +352,7 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
 }
 
 // numpy/renderer.py:145-163 + numpy/ops.py:88-115 on the host, in fp64, same operation order.
-int camera_to_frame(const SrhCamera* cam, FrameDev* F) {
+int camera_to_frame(const SrhCamera* cam, FrameDev* F, bool orthonormal = false) {
   if (!cam) return fail(SRH_E_NULL, "camera is NULL");
   const int W = cam->viewport[2] - cam->viewport[0], H = cam->viewport[3] - cam->viewport[1];
   if (W < 1 || H < 1) return fail(SRH_E_RANGE, "empty viewport %d x %d", W, H);
@@ -361,7 +365,16 @@ int camera_to_frame(const SrhCamera* cam, FrameDev* F) {
   if (!(zl > 0) || !(ul > 0)) return fail(SRH_E_CAMERA, "degenerate camera: eye == at or up == 0");
   double y[3];
   for (int i = 0; i < 3; ++i) { z[i] /= zl; y[i] = cam->up[i] / ul; }
-  const double x[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
+  double x[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
+  if (orthonormal) {
+    // torch backend (torch/utils.py:402-427): x = unit(cross(unit(up), z)), y = cross(z, x)
+    const double xl = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (!(xl > 0)) return fail(SRH_E_CAMERA, "degenerate camera: up is parallel to the view direction");
+    for (int i = 0; i < 3; ++i) x[i] /= xl;
+    y[0] = z[1] * x[2] - z[2] * x[1];
+    y[1] = z[2] * x[0] - z[0] * x[2];
+    y[2] = z[0] * x[1] - z[1] * x[0];
+  }
   const double h = tan(cam->fovy / 2) * 2 * cam->focal_length;
   const double w = h * ((double)W / (double)H);
   for (int i = 0; i < 3; ++i) { F->o[i] = cam->eye[i]; F->bx[i] = x[i]; F->by[i] = y[i]; F->bz[i] = z[i]; }
@@ -389,10 +402,13 @@ int setup_frame(const SrhCamera* camera, const SrhObjects* objects, const SrhLig
                 FrameDev* Fp, WsLayout* Lp) {
   FrameDev& F = *Fp;
   memset(&F, 0, sizeof(F));
-  int rc = camera_to_frame(camera, &F);
+  if (!params) return fail(SRH_E_NULL, "params is NULL");
+  if (params->shading != SRH_SHADING_NUMPY && params->shading != SRH_SHADING_TORCH)
+    return fail(SRH_E_TYPE, "unknown shading model %d", params->shading);
+  int rc = camera_to_frame(camera, &F, params->shading == SRH_SHADING_TORCH);
   if (rc) return rc;
   if ((rc = check_objects(objects))) return rc;
-  if (!lights || !materials || !params) return fail(SRH_E_NULL, "lights / materials / params is NULL");
+  if (!lights || !materials) return fail(SRH_E_NULL, "lights / materials is NULL");
   if ((rc = check_rows(F, params->row0, params->row1))) return rc;
   if (lights->n_lights < 0 || lights->n_lights > SRH_MAX_LIGHTS)
     return fail(SRH_E_RANGE, "n_lights = %d, expected 0..%d", lights->n_lights, SRH_MAX_LIGHTS);
@@ -422,6 +438,14 @@ int setup_frame(const SrhCamera* camera, const SrhObjects* objects, const SrhLig
   F.lcidx = lights->color_idx;
   F.colors = lights->colors;
   F.albedo = materials->albedo;
+  F.shading = params->shading;
+  F.double_sided = params->double_sided ? 1 : 0;
+  F.use_quartic = params->use_quartic ? 1 : 0;
+  F.latt = lights->attenuation;
+  F.ambient = lights->ambient;
+  F.coeffs = materials->coeffs;
+  F.normal_out = params->normal_out;
+  F.pos_out = params->pos_out;
   int first = 0;
   for (int s = 0; s < F.nseg; ++s) {
     const SrhSegment& g = objects->seg[s];
@@ -515,7 +539,8 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
   if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {
-    hipLaunchKernelGGL(k_render_binned, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
+    if (F.shading) hipLaunchKernelGGL(k_render_binned<true>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
+    else hipLaunchKernelGGL(k_render_binned<false>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
@@ -541,6 +566,8 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (rc) return rc;
   if (!grad_image || !nearest || !depth || !grads)
     return fail(SRH_E_NULL, "grad_image / nearest / depth / grads is NULL");
+  if (params->shading != SRH_SHADING_NUMPY)
+    return fail(SRH_E_TYPE, "the analytic backward covers SRH_SHADING_NUMPY only");
   GradsDev G;
   for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) {
     G.pos[s] = grads->pos[s]; G.normal[s] = grads->normal[s]; G.radius[s] = grads->radius[s]; G.face[s] = grads->face[s];

@@ -151,6 +151,7 @@ __device__ __forceinline__ float key_bound(uint32_t key) { return __uint_as_floa
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
 __device__ __forceinline__ float float_above(double t) { return (float)t * 1.0000005f; }
 
+template <bool TCH>
 __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, const double d[3], double& best,
                                                int& besti) {
   const int s = segment_of(F, gidx);
@@ -160,7 +161,7 @@ __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, cons
   for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
     if (s == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec64; }
   const double* R = base + (size_t)(gidx - first) * kRec64Stride[type];
-  resolve_lex(F, hit_any64(type, R, F.o, d), gidx, best, besti);
+  resolve_lex(F, hit_any64(type, R, F.o, d, TCH), gidx, best, besti);
 }
 
 // One reject record in registers: loaded with 16-byte accesses from a wave-uniform address, so the whole
@@ -280,7 +281,7 @@ struct SlowPixel {
   int g1, g2;         // already confirmed
 };
 
-template <int TYPE, bool PRETEST>
+template <int TYPE, bool PRETEST, bool TCH>
 __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
                                           uint32_t n, int lane, const SlowPixel& P, const double d[3],
                                           double& best, int& besti) {
@@ -291,7 +292,7 @@ __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, co
     bool cand[1], loose[1];
     float lo[1];
     pair_bounds<TYPE, PRETEST, 1>(R, P.cf, P.rf, P.len, cand, loose, lo);
-    if ((loose[0] || (cand[0] && lo[0] <= P.bound)) && g != P.g1 && g != P.g2) confirm_global(F, g, d, best, besti);
+    if ((loose[0] || (cand[0] && lo[0] <= P.bound)) && g != P.g1 && g != P.g2) confirm_global<TCH>(F, g, d, best, besti);
   }
 }
 
@@ -367,7 +368,7 @@ __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, ui
 
 // Resolve the pixel of lane `src` on the slow path with the whole wave; returns the merged (t, index) minimum of
 // everything confirmed here (index 0x7fffffff = nothing), valid in every lane.
-template <bool PRETEST>
+template <bool PRETEST, bool TCH>
 __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane, int src, float cf, float rf,
                                            float len, float bound, int g1, int g2, const double d[3],
                                            double& out_t, int& out_i) {
@@ -389,10 +390,10 @@ __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
       switch (S.type) {
-        case SRH_PRIM_DISK: slow_list<SRH_PRIM_DISK, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
-        case SRH_PRIM_PLANE: slow_list<SRH_PRIM_PLANE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
-        case SRH_PRIM_SPHERE: slow_list<SRH_PRIM_SPHERE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
-        default: slow_list<SRH_PRIM_TRIANGLE, PRETEST>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_DISK: slow_list<SRH_PRIM_DISK, PRETEST, TCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_PLANE: slow_list<SRH_PRIM_PLANE, PRETEST, TCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_SPHERE: slow_list<SRH_PRIM_SPHERE, PRETEST, TCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        default: slow_list<SRH_PRIM_TRIANGLE, PRETEST, TCH>(F, S, list, n, lane, P, ds, best, besti); break;
       }
     }
   }
@@ -411,6 +412,7 @@ struct alignas(16) Parked {
   uint32_t k1, k2, k3, k4;
 };
 
+template <bool TCH>
 __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte accesses
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
             const int g = ordinal_to_global(F, tile, key & kOrdMask);
             if (q == 0) g1 = g;
             if (q == 1) g2 = g;
-            confirm_global(F, g, d, best, besti);
+            confirm_global<TCH>(F, g, d, best, besti);
             bound = float_above(best);
           }
         }
@@ -498,8 +500,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       todo &= todo - 1;
       double st;
       int si;
-      if (pretest) slow_pixel<true>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
-      else slow_pixel<false>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+      if (pretest) slow_pixel<true, TCH>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+      else slow_pixel<false, TCH>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
       if (lane == src && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
         best = st;
         besti = si;
@@ -507,16 +509,18 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
     }
 #endif
     if (besti == 0x7fffffff) besti = 0;       // nothing hit: np.argmin of an all-inf column
-    float rgb[3];
+    float rgb[3], aux[6];
+    const bool want_aux = F.normal_out || F.pos_out;
 #ifdef SRH_ABL_NOSHADE
     rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __uint_as_float(p.k1);
 #else
-    shade_pixel(F, d, best, besti, rgb);
+    shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr);
 #endif
     if (row_live && c0 + j < F.W) {
       float* px = image + row * F.img_stride + 3 * (size_t)(c0 + j);
       px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
-      depth[row * F.depth_stride + (c0 + j)] = (float)best;
+      depth[row * F.depth_stride + (c0 + j)] = background_depth(F, best);
+      if (want_aux) store_aux(F, row, c0 + j, aux);
 #ifdef SRH_DIAG_AGAIN   // diagnostic build: did this pixel take the slow path (1 = nothing confirmed yet, 2 = third bound)
       if (nearest) nearest[row * F.near_stride + (c0 + j)] = !slow ? 0 : (bound == __builtin_inff() ? 1 : 2);
 #else

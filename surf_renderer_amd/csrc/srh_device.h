@@ -42,6 +42,13 @@ struct FrameDev {
   int32_t W, H, row0, row1;
   int32_t nseg, total, nlights, ncolors, nmat, tonemap;
   int64_t img_stride, depth_stride, near_stride;   // elements per output row
+  // SRH_SHADING_TORCH extras (torch/renderer.py:82-125)
+  int32_t shading, double_sided, use_quartic, pad2;
+  const float* latt;                 // (L,3) attenuation or NULL
+  const float* coeffs;               // (K,3) material coefficients or NULL
+  const float* ambient;              // (3) or NULL
+  float* normal_out;                 // optional (rows,W,3)
+  float* pos_out;                    // optional (rows,W,3)
   // tile binning (BINNED mode): 16x16-pixel tiles over the rendered row slab
   int32_t tiles_x, tiles_y, ntiles, ntiles_pad;   // ntiles_pad = ntiles rounded up to a multiple of 4
   int32_t nbins, pad1;                            // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile
@@ -132,11 +139,25 @@ __device__ __forceinline__ double hit_triangle64(const double* R, const double o
   return inside ? t : __builtin_inf();
 }
 
-__device__ __forceinline__ double hit_any64(int type, const double* R, const double o[3], const double d[3]) {
+// sphere under the torch backend's semantics (torch/utils.py:238-279), with its data-dependent sentinels replaced
+// by what they stand for: a negative root or a missed line is a miss
+__device__ __forceinline__ double hit_sphere64_tch(const double* R, const double d[3]) {
+  const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+  const double b = 2.0 * dot3(R, d);
+  const double disc = b * b - 4.0 * a * R[3];
+  if (!(disc >= 0.0)) return __builtin_inf();
+  const double root = sqrt(disc);
+  const double t1 = (-b - root) / (2.0 * a), t2 = (-b + root) / (2.0 * a);
+  const double inf = __builtin_inf();
+  return fmin(t1 >= 0.0 ? t1 : inf, t2 >= 0.0 ? t2 : inf);
+}
+
+__device__ __forceinline__ double hit_any64(int type, const double* R, const double o[3], const double d[3],
+                                            bool tch = false) {
   switch (type) {
     case SRH_PRIM_DISK: return hit_disk64(R, d);
     case SRH_PRIM_PLANE: return hit_plane64(R, d);
-    case SRH_PRIM_SPHERE: return hit_sphere64(R, d);
+    case SRH_PRIM_SPHERE: return tch ? hit_sphere64_tch(R, d) : hit_sphere64(R, d);
     default: return hit_triangle64(R, o, d);
   }
 }
@@ -154,6 +175,18 @@ __device__ __forceinline__ void resolve_lex(const FrameDev& F, double t, int gid
     best = t;
     besti = gidx;
   }
+}
+
+// depth as stored: the numpy backend leaves +inf where nothing is hit (numpy/renderer.py:228), the torch backend
+// far + 1 (torch/renderer.py:180-183)
+__device__ __forceinline__ float background_depth(const FrameDev& F, double z) {
+  return (F.shading && !(z <= F.far_clip)) ? (float)(F.far_clip + 1.0) : (float)z;
+}
+
+__device__ __forceinline__ void store_aux(const FrameDev& F, size_t row, int c, const float aux[6]) {
+  const size_t p = (row * (size_t)F.W + (size_t)c) * 3;
+  if (F.normal_out) { F.normal_out[p] = aux[0]; F.normal_out[p + 1] = aux[1]; F.normal_out[p + 2] = aux[2]; }
+  if (F.pos_out) { F.pos_out[p] = aux[3]; F.pos_out[p + 1] = aux[4]; F.pos_out[p + 2] = aux[5]; }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -183,9 +216,14 @@ __device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
 // the light loop and go straight to tonemap(0).
 // Arithmetic is fp64; vectors are normalised by multiplying with rsqrt_newton(|v|^2) instead of dividing
 // each component by sqrt(|v|^2) (equal to ~1e-16, immaterial after the fp32 store).
-__device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3], double z, int win,
-                                            float rgb[3]) {
+template <bool TCH>
+__device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
+                                              float rgb[3], float aux[6] = nullptr) {
   const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
+  if (aux) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) aux[i] = 0.0f;
+  }
   if (masked) {
     rgb[0] = rgb[1] = rgb[2] = tonemap_f32(F, 0.0);
     return;
@@ -207,8 +245,10 @@ __device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3]
     const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : (0.0 / len2);
     bool ok;
     (void)hit_sphere64(S.rec64 + 4 * (size_t)li, d, &ok);
+    // the torch backend normalises with its eps: v / sqrt(|v|^2 + 3e-10) (torch/utils.py:131-135)
+    const double inv_t = (len2 + 3.0e-10 > 0.0) ? rsqrt_newton(len2 + 3.0e-10) : 1.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) n[i] = ok ? v[i] * inv : 0.0;
+    for (int i = 0; i < 3; ++i) n[i] = TCH ? v[i] * inv_t : (ok ? v[i] * inv : 0.0);
   } else {
     // unit normal as k_prep normalised it (ops.normalize, zero vectors stay zero, numpy/ops.py:18-26)
     const double* R = S.rec64 + (size_t)li * kRec64Stride[S.type];
@@ -216,8 +256,47 @@ __device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3]
   }
   const int m = clampi(S.mat[li], 0, F.nmat - 1);
   const double alb[3] = {(double)F.albedo[3 * m], (double)F.albedo[3 * m + 1], (double)F.albedo[3 * m + 2]};
+  if (aux) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { aux[i] = (float)n[i]; aux[3 + i] = (float)p[i]; }
+  }
 
   double im[3] = {0.0, 0.0, 0.0};
+  if (TCH) {
+    // Phong fragment shader of the torch backend (torch/renderer.py:82-125)
+    const double cf[3] = {F.coeffs ? (double)F.coeffs[3 * m] : 1.0, F.coeffs ? (double)F.coeffs[3 * m + 1] : 0.0,
+                          F.coeffs ? (double)F.coeffs[3 * m + 2] : 0.0};
+    const double cv[3] = {F.o[0] - p[0], F.o[1] - p[1], F.o[2] - p[2]};
+    const double cinv = rsqrt_newton(((cv[0] * cv[0] + cv[1] * cv[1]) + cv[2] * cv[2]) + 3.0e-10);
+    const double cdir[3] = {cv[0] * cinv, cv[1] * cinv, cv[2] * cinv};
+    const double cdotn = (cdir[0] * n[0] + cdir[1] * n[1]) + cdir[2] * n[2];
+    const double sgn = F.double_sided ? ((cdotn > 0.0) ? 1.0 : ((cdotn < 0.0) ? -1.0 : 0.0)) : 1.0;
+    for (int l = 0; l < F.nlights; ++l) {
+      const float* lp = F.lpos + 4 * l;
+      const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
+      const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+      const double dist = sqrt(len2);
+      const double inv = (dist > 0.0) ? 1.0 / dist : 1.0;
+      const double lh[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+      const double kc = F.latt ? (double)F.latt[3 * l] : 1.0, kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0,
+                   kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
+      const double dp = F.use_quartic ? (len2 * len2) : len2;
+      const double den = (kc + dist * kl) + dp * kq;
+      const double afac = 1.0 / ((fabs(den) > 0.0) ? den : 1.0);
+      const double ldn = (lh[0] * n[0] + lh[1] * n[1]) + lh[2] * n[2];
+      double ndotl = sgn * (afac * ldn);
+      // reflect_ray(-l^, n) = 2 (l^.n) n - l^ ;  dotted with the view direction
+      double rdotc = sgn * (2.0 * ldn * cdotn - ((cdir[0] * lh[0] + cdir[1] * lh[1]) + cdir[2] * lh[2]));
+      ndotl = fmax(ndotl, 0.0);
+      rdotc = fmax(rdotc, 0.0);
+      const double spec = (cf[1] != 0.0) ? cf[1] * pow(rdotc, cf[2]) : 0.0;
+      const double w = cf[0] * ndotl + spec;
+      const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)      // the ambient term is added once per light, as the reference does (:116-121)
+        im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + (F.ambient ? (double)F.ambient[ch] : 0.0) * alb[ch];
+    }
+  } else
   for (int l = 0; l < F.nlights; ++l) {
     const float* lp = F.lpos + 4 * l;
     const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
@@ -235,6 +314,13 @@ __device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3]
     if (v < 0.0) v = 0.0;                                         // :259, NaN stays NaN
     rgb[ch] = tonemap_f32(F, v);                                  // :262-263
   }
+}
+
+// runtime dispatch on the frame's shading model (kernels on the hot path instantiate shade_pixel_t directly)
+__device__ __forceinline__ void shade_pixel(const FrameDev& F, const double d[3], double z, int win,
+                                            float rgb[3], float aux[6] = nullptr) {
+  if (F.shading) shade_pixel_t<true>(F, d, z, win, rgb, aux);
+  else shade_pixel_t<false>(F, d, z, win, rgb, aux);
 }
 
 }  // namespace srh

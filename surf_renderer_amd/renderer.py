@@ -27,8 +27,7 @@ from .scene import PRIM_CODE, _OBJ_FIELDS
 
 # keyword arguments of the torch backend's render() that callers pass routinely (torch/renderer.py:
 # 152-168, 233-245, 291, 326-327); the hip backend accepts them so call sites need no edits.
-_TORCH_ONLY_KWARGS = {"tiled", "tile_size", "backface_culling", "norm_depth_image_only", "vis_stat",
-                      "shadow", "double_sided", "use_quartic"}
+_TORCH_ONLY_KWARGS = {"tiled", "tile_size", "backface_culling", "norm_depth_image_only", "vis_stat", "shadow"}
 
 
 def _require_gpu(device: torch.device) -> None:
@@ -181,6 +180,23 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
     ls = _lib.SrhLights(n_lights=lpos.shape[0], n_colors=colors.shape[0], pos=lpos.data_ptr(),
                         color_idx=lidx.data_ptr(), colors=colors.data_ptr())
     ms = _lib.SrhMaterials(n_materials=albedo.shape[0], albedo=albedo.data_ptr())
+    # inputs of the torch backend's shading model only (ignored by the numpy one, numpy/renderer.py:234-255)
+    if "attenuation" in lights:
+        att = _as_tensor(lights["attenuation"], f32, device).reshape(-1, 3)
+        if att.shape[0] != lpos.shape[0]:
+            raise ValueError("lights.attenuation must have one (kc, kl, kq) row per light")
+        tensors["lights.attenuation"] = att
+        ls.attenuation = att.data_ptr()
+    if "ambient" in lights:
+        amb = _as_tensor(lights["ambient"], f32, device).reshape(3)
+        tensors["lights.ambient"] = amb
+        ls.ambient = amb.data_ptr()
+    if "coeffs" in scene["materials"]:
+        cfs = _as_tensor(scene["materials"]["coeffs"], f32, device).reshape(-1, 3)
+        if cfs.shape[0] != albedo.shape[0]:
+            raise ValueError("materials.coeffs must have one row per material")
+        tensors["materials.coeffs"] = cfs
+        ms.coeffs = cfs.data_ptr()
 
     gamma = None
     if "tonemap" in scene:
@@ -247,11 +263,15 @@ def _stream_ptr(device: torch.device) -> int:
 def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                    mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
                    want_nearest: bool = True, events: Optional[_lib.EventPair] = None,
-                   workspace: Optional[torch.Tensor] = None):
+                   workspace: Optional[torch.Tensor] = None, shading: str = "numpy", double_sided: bool = False,
+                   use_quartic: bool = False, aux: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None):
     """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
     enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
     preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None).  ``workspace`` overrides the
-    buffers' own scratch: frames in flight on different streams each need their own (``new_workspace``)."""
+    buffers' own scratch: frames in flight on different streams each need their own (``new_workspace``).
+    ``shading='torch'`` selects the torch backend's semantics (Phong with attenuation / specular / ambient,
+    ``double_sided``, ``use_quartic``, orthonormal camera, far+1 background); ``aux=(normal, pos)`` are optional
+    dense (h,W,3) f32 outputs."""
     lib = _lib.load()
     width, height = frame_size(cam)
     r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
@@ -273,6 +293,10 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
     params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[mode],
                             tonemap_gamma=0 if buf.gamma is None else 1,
                             gamma=1.0 if buf.gamma is None else buf.gamma,
+                            shading=_lib.SHADING[shading], double_sided=int(bool(double_sided)),
+                            use_quartic=int(bool(use_quartic)),
+                            normal_out=aux[0].data_ptr() if aux and aux[0] is not None else None,
+                            pos_out=aux[1].data_ptr() if aux and aux[1] is not None else None,
                             image_row_stride=image.stride(0) if h > 1 else 0,
                             depth_row_stride=depth.stride(0) if h > 1 else 0,
                             nearest_row_stride=nearest.stride(0) if (nearest is not None and h > 1) else 0,
@@ -393,17 +417,39 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     ``diffrend.numpy.renderer.render`` within fp32 rounding of the stored outputs.
 
     Keyword arguments: ``device`` ('cuda'), ``mode`` ('auto' | 'exact' | 'fast' | 'binned'), ``rows`` ((r0, r1) slab),
-    ``validate`` (host-side index / w checks).  The torch backend's kwargs (tiled, tile_size, shadow, ...)
-    are accepted and ignored: the numpy backend this one matches has none of those features.
+    ``validate`` (host-side index / w checks), ``shading`` ('numpy' | 'torch').  With ``shading='torch'`` the call
+    follows ``diffrend.torch.renderer.render`` instead (Phong shading with lights.attenuation / lights.ambient /
+    materials.coeffs, ``double_sided``, ``use_quartic``, orthonormal camera basis, far+1 background, extra outputs
+    ``normal`` and ``pos``; forward only).  The torch backend's remaining kwargs (tiled, tile_size, ...) are accepted
+    and ignored.
     """
-    unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate"}
+    unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate", "shading", "double_sided",
+                                                  "use_quartic"}
     if unknown:
         raise TypeError(f"render() got unexpected keyword arguments {sorted(unknown)}")
     device = torch.device(params.get("device", "cuda"))
     buf = flatten_scene(scene, device, validate=params.get("validate", True), keep_graph=torch.is_grad_enabled())
     cam = camera_struct(scene["camera"])
     rows, mode = params.get("rows"), params.get("mode", "auto")
+    shading = params.get("shading", "numpy")
+    if shading not in _lib.SHADING:
+        raise ValueError(f"shading must be 'numpy' or 'torch', got {shading!r}")
+    if params.get("shadow"):
+        raise NotImplementedError("shadow rays (torch/renderer.py:291-314) are not implemented by the hip backend")
     inputs = [buf.tensors[k] for k in _float_keys(buf)]
+    if shading == "torch":
+        # the torch backend's semantics (SURVEY section 8, row f1): forward only
+        if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
+            raise NotImplementedError("shading='torch' has no analytic backward yet; use shading='numpy'")
+        width, height = frame_size(cam)
+        r0, r1 = (0, height) if rows is None else rows
+        normal = torch.empty((r1 - r0, width, 3), dtype=torch.float32, device=device)
+        pos = torch.empty((r1 - r0, width, 3), dtype=torch.float32, device=device)
+        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode, shading="torch",
+                                               double_sided=params.get("double_sided", False),
+                                               use_quartic=params.get("use_quartic", False), aux=(normal, pos))
+        return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64),
+                            normal=normal, pos=pos)
     if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
         # differentiable call: image and depth carry a grad_fn backed by the analytic HIP backward
         image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, *inputs)

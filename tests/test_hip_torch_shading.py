@@ -1,0 +1,57 @@
+"""GPU: render(scene, shading='torch') -- the torch backend's semantics -- against the
+reference torch backend's own outputs (tests/golden/t*.npz, float32) and the fp64 oracle of those semantics.
+
+Tolerances: against the float32 reference as in tests/test_oracle_tch.py (<= 0.5 % of pixels may differ in hit /
+nearest at silhouettes; depth 2e-5 relative, image / normal 3e-4, pos 2e-4 elsewhere); against the fp64 oracle
+`nearest` identical, depth one fp32 ulp, image 2e-7 + 2e-6 |x|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle_tch
+from test_oracle_tch import CASES, assert_tch_parity, load_tch_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(scene, **kw):
+    from surf_renderer_amd import render
+    res = render(scene, device="cuda:0", shading="torch", **kw)
+    torch.cuda.synchronize()
+    return {k: res[k].cpu().numpy() for k in ("image", "depth", "nearest", "normal", "pos")}
+
+
+@pytest.mark.parametrize("mode", ["exact", "binned"])
+@pytest.mark.parametrize("case", CASES)
+def test_torch_shading_matches_reference_torch_backend(case, mode):
+    scene, want, kw = load_tch_case(case)
+    got = _render(scene, mode=mode, **kw)
+    assert_tch_parity(got, want, scene["camera"]["far"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_torch_shading_matches_fp64_oracle(case):
+    scene, _, kw = load_tch_case(case)
+    want = np_oracle_tch.render(scene, **kw)
+    got = _render(scene, **kw)
+    far = scene["camera"]["far"]
+    np.testing.assert_array_equal(got["nearest"], want["nearest"])
+    np.testing.assert_allclose(got["depth"], want["depth"], rtol=1.2e-7)
+    np.testing.assert_allclose(got["image"], want["image"], rtol=2e-6, atol=2e-7)
+    hit = want["depth"] <= far
+    np.testing.assert_allclose(got["normal"][hit], want["normal"][hit], atol=2e-7)
+    np.testing.assert_allclose(got["pos"][hit], want["pos"][hit], rtol=2e-7, atol=2e-6)
+    assert np.all(got["normal"][~hit] == 0) and np.all(got["pos"][~hit] == 0)
+
+
+def test_torch_shading_modes_identical_and_numpy_default_unchanged():
+    from surf_renderer_amd import render, synthetic
+    scene = synthetic.splat_basic_scene(200, 150)
+    a = _render(scene, mode="exact", double_sided=True)
+    b = _render(scene, mode="binned", double_sided=True)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    plain = render(scene, device="cuda:0")
+    assert "normal" not in plain and torch.isinf(plain["depth"]).any()
+    with pytest.raises(NotImplementedError):
+        render(scene, device="cuda:0", shading="torch", shadow=True)
