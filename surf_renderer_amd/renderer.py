@@ -390,6 +390,48 @@ class _RenderFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.get(k) for k in keys)
 
 
+def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], device="cuda", mode: str = "auto",
+                 streams: int = 4, want_nearest: bool = True, **shading_kw) -> Dict[str, torch.Tensor]:
+    """Many cameras, one scene: the batch axis of the reference's real callers (one ``render()`` per view in a
+    Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once; views
+    are issued round-robin over ``streams`` HIP streams, each with its own scratch, so the small latency-bound
+    kernels of one view overlap the others.  All cameras must share one viewport size.  Returns stacked tensors
+    ``image`` (B,H,W,3), ``depth`` (B,H,W) and ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` /
+    ``use_quartic`` as in ``render``.  Forward only."""
+    device = torch.device(device)
+    buf = flatten_scene(scene, device)
+    cams = [camera_struct(c) for c in cameras]
+    if not cams:
+        raise ValueError("no cameras")
+    width, height = frame_size(cams[0])
+    if any(frame_size(c) != (width, height) for c in cams):
+        raise ValueError("all cameras of a batch must have the same viewport size")
+    n = len(cams)
+    image = torch.empty((n, height, width, 3), dtype=torch.float32, device=device)
+    depth = torch.empty((n, height, width), dtype=torch.float32, device=device)
+    nearest = torch.empty((n, height, width), dtype=torch.int32, device=device) if want_nearest else None
+    n_streams = max(1, min(int(streams), n))
+    pool = [torch.cuda.Stream(device) for _ in range(n_streams)]
+    scratch = [buf.new_workspace(width, height) for _ in range(n_streams)]
+    current = torch.cuda.current_stream(device)
+    for st in pool:
+        st.wait_stream(current)                 # uploads and allocations above happen-before the views
+    for i, cam in enumerate(cams):
+        k = i % n_streams
+        with torch.cuda.stream(pool[k]):
+            render_buffers(buf, cam, mode=mode, out=(image[i], depth[i], nearest[i] if want_nearest else None),
+                           workspace=scratch[k], **shading_kw)
+    for st in pool:
+        current.wait_stream(st)
+    for t in (image, depth, nearest, *scratch, *buf.tensors.values()):
+        if t is not None:
+            t.record_stream(current)
+    out = {"image": image, "depth": depth}
+    if want_nearest:
+        out["nearest"] = nearest
+    return out
+
+
 class RenderResult(dict):
     """The reference's result dict.  ``image`` (H,W,3), ``depth`` (H,W) and ``nearest`` (H,W) are always
     present; ``ray_dir`` (4,N) is produced on first access.  The three O(M*N) entries of the numpy

@@ -207,3 +207,26 @@ def test_long_tile_lists_saturate_the_ordinal():
     _modes_identical(scene, modes=("exact", "binned"))
     scene["camera"]["near"] = 0.0
     _modes_identical(scene, modes=("exact", "binned"))
+
+
+def test_render_views_equals_per_view_render():
+    """Batched multi-view rendering (several streams, shared scene) returns exactly what render() returns per view."""
+    from surf_renderer_amd import render, render_views, synthetic
+    scene = synthetic.bunny_splat_scene(96, 80)
+    rng = np.random.RandomState(5)
+    cams = []
+    for _ in range(7):
+        cam = dict(scene["camera"])
+        eye = rng.normal(size=3)
+        eye = 10.0 * eye / np.linalg.norm(eye)
+        cam["eye"] = [float(eye[0]), float(eye[1]), float(eye[2]), 1.0]
+        cams.append(cam)
+    batch = render_views(scene, cams, device="cuda:0", streams=3)
+    torch.cuda.synchronize()
+    assert batch["image"].shape == (7, 80, 96, 3)
+    for i, cam in enumerate(cams):
+        single = render({**scene, "camera": cam}, device="cuda:0")
+        np.testing.assert_array_equal(batch["image"][i].cpu().numpy(), single["image"].cpu().numpy())
+        np.testing.assert_array_equal(batch["depth"][i].cpu().numpy(), single["depth"].cpu().numpy())
+        np.testing.assert_array_equal(batch["nearest"][i].cpu().numpy(), single["nearest"].cpu().numpy())
+    assert np.isfinite(batch["depth"].cpu().numpy()).mean() > 0.05

@@ -65,5 +65,21 @@ def main():
                       "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt}), flush=True)
 
 
+def batched_views():
+    """f4: 64 views of bunny.splat at 128x128 (the GAN's regime: many small renders of one scene)."""
+    scene = synthetic.bunny_splat_scene(128, 128)
+    rng = np.random.RandomState(0)
+    cams = []
+    for _ in range(64):
+        eye = rng.normal(size=3)
+        eye = 10.0 * eye / np.linalg.norm(eye)
+        cams.append(dict(scene["camera"], eye=[float(eye[0]), float(eye[1]), float(eye[2]), 1.0]))
+    for streams in (1, 4, 8):
+        dt = timed(lambda: renderer.render_views(scene, cams, device="cuda:0", streams=streams), steps=10, warmup=2)
+        print(json.dumps({"config": f"f4: 64 views x bunny.splat 128x128, {streams} stream(s), scene upload included",
+                          "ms_per_batch": 1e3 * dt, "views_per_s": 64 / dt}), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    batched_views()
