@@ -120,6 +120,39 @@ def obj_to_triangle_spec(obj: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return {"face": face, "normal": normal}
 
 
+def circum_circles(v: np.ndarray, f: np.ndarray) -> Dict[str, np.ndarray]:
+    """Circumscribed circle of every triangle (centre, radius), from cross / dot products as the reference does
+    (model.py:35-63): with a = p1-p2, b = p2-p3, c = p1-p3 and n = a x b,
+    radius = |a||b||c| / (2|n|), centre = alpha p1 + beta p2 + gamma p3 with the barycentric weights below."""
+    p1, p2, p3 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    p23, p13, p12 = p2 - p3, p1 - p3, p1 - p2
+    n2 = np.sum(np.cross(p12, p23) ** 2, axis=-1)
+    length = lambda x: np.sqrt(np.sum(x ** 2, axis=-1))  # noqa: E731
+    radius = length(p12) * length(p23) * length(p13) / (2 * np.sqrt(n2))
+    inv = 1.0 / (2 * n2)
+    alpha = np.sum(p23 ** 2, axis=-1) * np.sum(p12 * p13, axis=-1) * inv
+    beta = np.sum(p13 ** 2, axis=-1) * np.sum(-p12 * p23, axis=-1) * inv
+    gamma = np.sum(p12 ** 2, axis=-1) * np.sum(p13 * p23, axis=-1) * inv
+    centre = alpha[:, None] * p1 + beta[:, None] * p2 + gamma[:, None] * p3
+    return {"center": centre, "radius": radius}
+
+
+def obj_to_splat(obj: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Mesh -> disc splats: one disc per face, the face's circumscribed circle with the face normal
+    (model.py:66-75; this is how the reference's data/bunny.splat was made from data/bunny.obj)."""
+    cc = circum_circles(obj["v"], obj["f"])
+    return {"v": cc["center"], "r": cc["radius"], "vn": face_normals(obj["v"], obj["f"]), "type": "splat"}
+
+
+def write_splat(path: str, splat: Dict[str, np.ndarray]) -> None:
+    """The reference's text format: `v x y z` / `vn x y z` / `r radius` per disc (model.py:78-87)."""
+    with open(path, "w") as fh:
+        for v, vn, r in zip(splat["v"], splat["vn"], np.asarray(splat["r"]).reshape(len(splat["v"]), -1)):
+            fh.write("v " + " ".join(repr(float(x)) for x in v) + "\n")
+            fh.write("vn " + " ".join(repr(float(x)) for x in vn) + "\n")
+            fh.write("r " + " ".join(repr(float(x)) for x in r) + "\n")
+
+
 def axis_angle_matrix(axis, angle: float) -> np.ndarray:
     """3x3 rotation about ``axis`` by ``angle`` radians, built the way the reference does: unit
     quaternion (cos a/2, sin a/2 * axis/|axis|) then the s = 2/|q|^2 matrix

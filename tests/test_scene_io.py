@@ -117,3 +117,19 @@ def test_disk_cloud_is_seeded_and_fp32_representable():
         np.testing.assert_array_equal(arr, arr.astype(np.float32).astype(np.float64))
     assert np.all(a["objects"]["disk"]["normal"][:, 2] >= 0)
     np.testing.assert_allclose(np.linalg.norm(a["objects"]["disk"]["normal"][:, :3], axis=1), 1.0, atol=1e-6)
+
+
+def test_obj_to_splat_reproduces_the_shipped_bunny_splat(tmp_path):
+    """data/bunny.splat is the circum-circle splat conversion of data/bunny.obj (model.py:35-75): our conversion of
+    the shipped mesh must reproduce the shipped splat file, and survive a write / load round trip."""
+    obj = sio.load_obj(os.path.join(synthetic.ASSETS, "data", "bunny.obj"))
+    want = sio.load_splat(os.path.join(synthetic.ASSETS, "data", "bunny.splat"))
+    got = sio.obj_to_splat(obj)
+    np.testing.assert_allclose(got["v"], want["v"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got["vn"], want["vn"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got["r"], want["r"].ravel(), rtol=1e-9)
+    path = tmp_path / "round.splat"
+    sio.write_splat(str(path), got)
+    back = sio.load_splat(str(path))
+    np.testing.assert_array_equal(back["v"], got["v"])
+    np.testing.assert_array_equal(back["r"].ravel(), got["r"])
