@@ -238,35 +238,46 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
   }
 }
 
+// One staged primitive against the lane's four pixels: update the keys.
+template <int TYPE, bool PRETEST>
+__device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_t ord, QuadState& Q) {
+  bool cand[4], loose[4];
+  float lo[4];
+  pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, loose, lo);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t ranked = (__float_as_uint(lo[j]) & ~kOrdMask) | ord;
+    const uint32_t key = loose[j] ? ord : (cand[j] ? ranked : kNoKey);
+    Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
+    Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
+    Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
+    Q.k1[j] = min(Q.k1[j], key);
+  }
+}
+
 // The hot loop: fp32 only, straight-line, updates the per-pixel keys.  `ord0` = ordinal of the list's first entry.
+// Scalar loads complete out of order, so the only wait is "all of them": the loop is unrolled by two over two
+// record buffers A and B -- while A is evaluated, B's record (and the list word after it) is in flight, and the
+// wait for B comes only after A's ~100 vector instructions.  No register copies between the buffers.
 template <int TYPE, bool PRETEST>
 __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n,
                                            uint32_t ord0, QuadState& Q) {
   if (n == 0) return;
-  int g_next = (int)list[0];
-  int g_next2 = (int)list[n > 1 ? 1 : 0];
-  RejectRecord<TYPE> R_next;
-  R_next.load(S.rec32 + (size_t)(g_next - S.first) * kRec32Stride[TYPE]);
-  for (uint32_t i = 0; i < n; ++i) {
-    const RejectRecord<TYPE> R = R_next;
-    if (i + 1 < n) {
-      g_next = g_next2;
-      R_next.load(S.rec32 + (size_t)(g_next - S.first) * kRec32Stride[TYPE]);
-      g_next2 = (int)list[i + 2 < n ? i + 2 : i + 1];
-    }
-    const uint32_t ord = min(ord0 + i, kOrdMask);
-    bool cand[4], loose[4];
-    float lo[4];
-    pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, loose, lo);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t ranked = (__float_as_uint(lo[j]) & ~kOrdMask) | ord;
-      const uint32_t key = loose[j] ? ord : (cand[j] ? ranked : kNoKey);
-      Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
-      Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
-      Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
-      Q.k1[j] = min(Q.k1[j], key);
-    }
+  RejectRecord<TYPE> A, B;
+  const float* base = S.rec32;
+  const int first = S.first;
+  int gA = (int)list[0];
+  int gB = (int)list[n > 1 ? 1 : 0];
+  A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
+  for (uint32_t i = 0; i < n; i += 2) {
+    // B <- entry i+1 (clamped: reloading a valid record is harmless), then the list word of entry i+2
+    B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
+    gA = (int)list[min(i + 2, n - 1)];
+    sweep_entry<TYPE, PRETEST>(A, min(ord0 + i, kOrdMask), Q);
+    if (i + 1 >= n) break;
+    A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
+    gB = (int)list[min(i + 3, n - 1)];
+    sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 1, kOrdMask), Q);
   }
 }
 
