@@ -273,11 +273,15 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
     // B <- entry i+1 (clamped: reloading a valid record is harmless), then the list word of entry i+2
     B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
     gA = (int)list[min(i + 2, n - 1)];
+    __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
     sweep_entry<TYPE, PRETEST>(A, min(ord0 + i, kOrdMask), Q);
     if (i + 1 >= n) break;
+    __builtin_amdgcn_sched_barrier(0);
     A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
     gB = (int)list[min(i + 3, n - 1)];
+    __builtin_amdgcn_sched_barrier(0);
     sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 1, kOrdMask), Q);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
