@@ -292,7 +292,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t tilerange, counters, tile_off, large, entries;
+  size_t tilerange, tilemask, counters, tile_off, large, entries;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -338,6 +338,8 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   const size_t ntiles = ((size_t)L.tiles_x * L.tiles_y_max + 3) / 4 * 4;
   L.tilerange = off;
   off = align_up(off + total * 4 * sizeof(uint16_t));
+  L.tilemask = off;
+  off = align_up(off + total * sizeof(uint64_t));
   L.counters = off;
   L.counters_bytes = (kCounterPad + 2 * SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
   off = align_up(off + L.counters_bytes);
@@ -520,6 +522,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     F.nbins = F.nseg * F.ntiles_pad;
     char* ws = (char*)workspace;
     F.tilerange = (uint16_t*)(ws + L.tilerange);
+    F.tilemask = (uint64_t*)(ws + L.tilemask);
     F.counters = (uint32_t*)(ws + L.counters);
     F.tile_off = (uint32_t*)(ws + L.tile_off);
     F.large = (uint32_t*)(ws + L.large);

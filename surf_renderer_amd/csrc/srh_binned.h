@@ -51,9 +51,20 @@ __device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const
     return;
   }
   tr[0] = (uint16_t)tx0; tr[1] = (uint16_t)ty0; tr[2] = (uint16_t)tx1; tr[3] = (uint16_t)ty1;
+  // of the (at most 64) tiles of the box keep those the shape really reaches; bit k = k-th tile, row-major
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
+  uint64_t mask = 0;
+  int k = 0;
   for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&count[ty * F.tiles_x + tx], 1u);
+    for (int tx = tx0; tx <= tx1; ++tx, ++k) {
+      const double pc0 = tx * kTile, pr0 = F.row0 + ty * kTile;
+      if (shape_reaches_rect(type, rec32, pc0, fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr0,
+                             fmin(pr0 + kTile - 1, (double)(F.row1 - 1)))) {
+        mask |= 1ull << k;
+        atomicAdd(&count[ty * F.tiles_x + tx], 1u);
+      }
+    }
+  F.tilemask[gidx] = mask;
 }
 
 // ---- exclusive scan of the bin counts: one 1024-thread workgroup, 16-byte loads ---------------------------
@@ -100,7 +111,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
   const int bin0 = segment_of(F, gidx) * F.ntiles_pad;
   uint32_t* cursor = F.counters + kCounterPad + F.nbins;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+  const uint64_t mask = F.tilemask[gidx];
   for (int k = sub; k < n; k += 16) {
+    if (!((mask >> k) & 1ull)) continue;
     const int bin = bin0 + (ty0 + k / nx) * F.tiles_x + (tx0 + k % nx);
     const uint32_t slot = atomicAdd(&cursor[bin], 1u);
     F.entries[F.tile_off[bin] + slot] = (uint32_t)gidx;

@@ -53,6 +53,7 @@ struct FrameDev {
   int32_t tiles_x, tiles_y, ntiles, ntiles_pad;   // ntiles_pad = ntiles rounded up to a multiple of 4
   int32_t nbins, pad1;                            // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile
   uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
+  uint64_t* tilemask;                // (total) bit k = tile k of the range (row-major) really overlaps the shape
   uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts | [64+nbins, 64+2 nbins) fill cursors
   uint32_t* tile_off;                // (nbins+1) exclusive prefix of the bin counts
   uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)

@@ -297,4 +297,44 @@ __device__ inline BBox triangle_bbox(const float* rec) {
   return BBox{cmin - 1.0, cmax + 1.0, rmin - 1.0, rmax + 1.0, false};
 }
 
+// Does the stored reject shape reach the pixel rectangle [c0,c1] x [r0,r1] (inclusive pixel coordinates)?  Used to drop
+// tiles of a primitive's bounding box that its shape misses (box corners of round or slanted shapes).  A tile may
+// be dropped only if no pixel in it can be a true hit; true hits lie inside the stored (inflated) shape, so the
+// exact fp64 minimum of the stored form over the rectangle being > 1 (ellipse), or one stored edge function being
+// negative at all four corners (triangle), proves that.
+__device__ inline bool shape_reaches_rect(int type, const float* rec, double c0, double c1, double r0, double r1) {
+  if (type == SRH_PRIM_TRIANGLE) {
+    for (int i = 0; i < 3; ++i) {
+      const double a = rec[4 * i], b = rec[4 * i + 1], g = rec[4 * i + 2];
+      if (a * (a > 0.0 ? c1 : c0) + b * (b > 0.0 ? r1 : r0) + g < 0.0) return false;
+    }
+    return true;
+  }
+  if (type != SRH_PRIM_DISK && type != SRH_PRIM_SPHERE) return true;
+  double A11, A12, A22;
+  if (rec[11] > 0.0f) {                                    // principal-axes form -> quadratic form
+    const double ex = rec[2], ey = rec[3], iu2 = (double)rec[4] * rec[4], iv2 = (double)rec[11] * rec[11];
+    A11 = ex * ex * iu2 + ey * ey * iv2;
+    A12 = ex * ey * (iu2 - iv2);
+    A22 = ey * ey * iu2 + ex * ex * iv2;
+  } else {
+    A11 = rec[2]; A12 = 0.5 * (double)rec[3]; A22 = rec[4];
+  }
+  if (!(A11 > 0.0) || !(A22 > 0.0)) return true;           // "always a candidate"
+  const double x0 = (double)rec[0], y0 = (double)rec[1];
+  if (x0 >= c0 && x0 <= c1 && y0 >= r0 && y0 <= r1) return true;
+  auto Q = [&](double dc, double dr) { return A11 * dc * dc + 2.0 * A12 * dc * dr + A22 * dr * dr; };
+  double qmin = 1e300;
+  // vertical edges c = c0, c1: minimise over dr; horizontal edges r = r0, r1: minimise over dc
+  for (int e = 0; e < 2; ++e) {
+    const double dc = (e ? c1 : c0) - x0;
+    const double dr = fmin(fmax(-A12 * dc / A22, r0 - y0), r1 - y0);
+    qmin = fmin(qmin, Q(dc, dr));
+    const double dr2 = (e ? r1 : r0) - y0;
+    const double dc2 = fmin(fmax(-A12 * dr2 / A11, c0 - x0), c1 - x0);
+    qmin = fmin(qmin, Q(dc2, dr2));
+  }
+  return !(qmin > 1.000001);
+}
+
 }  // namespace srh
