@@ -540,7 +540,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
     hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * 16 + 255) / 256)), dim3(256), 0, st, F);
   }
-  if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
+  if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {
     if (F.shading) hipLaunchKernelGGL(k_render_binned<true>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
     else hipLaunchKernelGGL(k_render_binned<false>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
@@ -554,7 +554,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   } else {
     launch_fast<1>(F, st, image, depth, nearest);
   }
-  if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
+  if (params->ev_stop) (void)hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "render launch");
 }
@@ -586,9 +586,9 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                        (float*)S.rec32);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
-  if (params->ev_start) hipEventRecord((hipEvent_t)params->ev_start, st);
+  if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   hipLaunchKernelGGL(k_render_bwd, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
-  if (params->ev_stop) hipEventRecord((hipEvent_t)params->ev_stop, st);
+  if (params->ev_stop) (void)hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "backward launch");
 }

@@ -205,9 +205,18 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 }
 
 // image ** gamma of the tonemap (numpy/renderer.py:140-142) evaluated in fp32: x is already within half an
-// fp32 ulp of the reference value, powf adds ~2 ulp.
+// fp32 ulp of the reference value.  x^g = exp2(g * log2 x) on the hardware v_log_f32 / v_exp_f32 (1 ulp each):
+// the error of y = g log2 x is at most 2^-23 |y|, so with |y| <= 12 the result is off by at most
+// ln2 * 12 * 2^-23 + 2^-23 = 1.1e-6 relative (parity budget 2e-6).  Everything else -- zero, inf, nan, subnormal or
+// huge arguments, |y| > 12 -- takes the library powf (~2 ulp), so all special values are the reference's; only the
+// frequent 0^g (background, back-facing fragments) with g > 0 stays on the direct path.
 __device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
-  return F.tonemap ? powf((float)v, (float)F.gamma) : (float)v;
+  if (!F.tonemap) return (float)v;
+  const float x = (float)v, g = (float)F.gamma;
+  const float y = g * __builtin_amdgcn_logf(x);
+  const bool direct = (x >= 1e-30f && x <= 1e30f && fabsf(y) <= 12.0f) || (x == 0.0f && g > 0.0f);   // 0^g = exp2(-inf) = 0
+  if (direct) return __builtin_amdgcn_exp2f(y);
+  return powf(x, g);
 }
 
 // Fragment stage for one pixel (numpy/renderer.py:228-263): gathers the winner's normal / position /
