@@ -440,24 +440,53 @@ struct alignas(16) Parked {
   uint32_t k1, k2, k3, k4;
 };
 
+// inclusive prefix sum of one int per lane across the wave
+__device__ __forceinline__ int wave_prefix_incl(int v, int lane) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o = __shfl_up(v, m);
+    if (lane >= m) v += o;
+  }
+  return v;
+}
+
+// lanes below this one in a ballot mask
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The finish phase is COMPACTED: after the sweep the tile's pixels that have at least one candidate are queued
+// (row-major) in LDS and handed out 64 at a time, so a tile that is 40 % covered costs two fp64 rounds instead
+// of four; pixels without a candidate are background and stored straight away.
 template <bool TCH>
 __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
-  __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte accesses
+  __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
+  __shared__ uint8_t queue[4][256];           // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  if (tile >= F.ntiles) return;               // waves are independent: no barrier below, LDS slices are per wave
+  if (tile >= F.ntiles) return;               // waves are independent: no block barrier below, LDS slices are per wave
   const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-  const int c0 = tx * kTile + 4 * (lane & 3);
-  const int r_raw = F.row0 + ty * kTile + (lane >> 2);
-  const int r = min(r_raw, F.row1 - 1);
+  const int px0 = tx * kTile, py0 = F.row0 + ty * kTile;
+  const int c0 = px0 + 4 * (lane & 3);
+  const int r_raw = py0 + (lane >> 2);
+  const bool row_live = r_raw < F.row1;
 #ifdef SRH_ABL_NOPRETEST
   const bool pretest = false;
 #else
   const bool pretest = F.near_clip > 0.0;     // with near <= 0 a negative t can be valid: confirm every candidate
 #endif
+  const bool want_aux = F.normal_out || F.pos_out;
+  uint32_t has = 0;                           // bit j: pixel j of the quad exists and has a candidate
   {
+    const int r = min(r_raw, F.row1 - 1);
     QuadState Q;
     Q.rf = (float)r;
 #pragma unroll
@@ -475,85 +504,130 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       Parked p;
       p.k1 = Q.k1[j]; p.k2 = Q.k2[j]; p.k3 = Q.k3[j]; p.k4 = Q.k4[j];
       park[wave][j][lane] = p;
+      if (p.k1 != kNoKey && row_live && c0 + j < F.W) has |= 1u << j;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const bool row_live = r_raw < F.row1;
-  const size_t row = (size_t)(r - F.row0);
-#pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
-    const Parked p = park[wave][j][lane];
-    const int c = min(c0 + j, F.W - 1);
-    double d[3];
-    const float len = (float)pixel_ray(F, c, r, d);
-    double best = __builtin_inf();
-    int besti = 0x7fffffff;
-    float bound = __builtin_inff();
-    int g1 = -1, g2 = -1;
-    bool slow = false;
-#ifndef SRH_ABL_NOCONFIRM
-    if (p.k1 != kNoKey) {
-      // Confirm the front candidates in key order while their bound still reaches the confirmed depth (the
-      // first one always; the next ones after a near miss at an ellipse edge or for nearly coplanar primitives).
-      // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
-      const uint32_t keys[3] = {p.k1, p.k2, p.k3};
-      bool saturated = false;
+  // queue of the pixels with a candidate, row-major over the tile
+  int n1;
+  {
+    const int cnt = __popc(has);
+    const int incl = wave_prefix_incl(cnt, lane);
+    int pos = incl - cnt;
+    n1 = __builtin_amdgcn_readlane(incl, 63);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const uint32_t key = keys[q];
-        if (key != kNoKey && !saturated && key_bound(key) <= bound) {
-          if ((key & kOrdMask) == kOrdMask) {
-            saturated = true;
-          } else {
-            const int g = ordinal_to_global(F, tile, key & kOrdMask);
-            if (q == 0) g1 = g;
-            if (q == 1) g2 = g;
-            confirm_global<TCH>(F, g, d, best, besti);
-            bound = float_above(best);
+    for (int j = 0; j < 4; ++j)
+      if ((has >> j) & 1u) queue[wave][pos++] = (uint8_t)(j * 64 + lane);
+  }
+
+  // background: what the fragment stage gives an all-miss pixel (tonemap(0), +inf or far + 1, index 0)
+  if (row_live && has != 0xFu) {
+    const size_t row = (size_t)(r_raw - F.row0);
+    const float bg = tonemap_f32(F, 0.0);
+    const float bgz = background_depth(F, __builtin_inf());
+    float* px = image + row * F.img_stride + 3 * (size_t)c0;
+    float* dz = depth + row * F.depth_stride + c0;
+    int32_t* nr = nearest ? nearest + row * F.near_stride + c0 : nullptr;
+    const bool aligned = (((uintptr_t)px | (uintptr_t)dz | (uintptr_t)nr) & 15u) == 0;
+    if (has == 0 && c0 + 3 < F.W && aligned) {
+      const float4 v = make_float4(bg, bg, bg, bg);
+      reinterpret_cast<float4*>(px)[0] = v; reinterpret_cast<float4*>(px)[1] = v; reinterpret_cast<float4*>(px)[2] = v;
+      *reinterpret_cast<float4*>(dz) = make_float4(bgz, bgz, bgz, bgz);
+      if (nr) *reinterpret_cast<int4*>(nr) = make_int4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!((has >> j) & 1u) && c0 + j < F.W) {
+          px[3 * j] = bg; px[3 * j + 1] = bg; px[3 * j + 2] = bg;
+          dz[j] = bgz;
+          if (nr) nr[j] = 0;
+        }
+    }
+    if (want_aux) {
+      const float zero[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!((has >> j) & 1u) && c0 + j < F.W) store_aux(F, row, c0 + j, zero);
+    }
+  }
+
+  wave_lds_fence();                           // park / queue writes of other lanes
+#pragma unroll 1
+  for (int base = 0; base < n1; base += 64) {
+    {
+      const bool live = base + lane < n1;
+      const int id = live ? (int)queue[wave][base + lane] : 0;
+      const int j = id >> 6, src = id & 63;
+      const int c = px0 + 4 * (src & 3) + j, r = py0 + (src >> 2);
+      const Parked p = park[wave][j][src];
+      double d[3];
+      const float len = (float)pixel_ray(F, c, r, d);
+      double best = __builtin_inf();
+      int besti = 0x7fffffff;
+      float bound = __builtin_inff();
+      int g1 = -1, g2 = -1;
+      bool slow = false;
+#ifndef SRH_ABL_NOCONFIRM
+      if (live) {
+        // Confirm the front candidates in key order while their bound still reaches the confirmed depth (the
+        // first one always; the next ones after a near miss at an ellipse edge or for nearly coplanar primitives).
+        // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
+        const uint32_t keys[3] = {p.k1, p.k2, p.k3};
+        bool saturated = false;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const uint32_t key = keys[q];
+          if (key != kNoKey && !saturated && key_bound(key) <= bound) {
+            if ((key & kOrdMask) == kOrdMask) {
+              saturated = true;
+            } else {
+              const int g = ordinal_to_global(F, tile, key & kOrdMask);
+              if (q == 0) g1 = g;
+              if (q == 1) g2 = g;
+              confirm_global<TCH>(F, g, d, best, besti);
+              bound = float_above(best);
+            }
           }
         }
+        // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
+        slow = saturated || (p.k4 != kNoKey && key_bound(p.k4) <= bound);
+        if (slow) { g1 = g2 = -1; }           // the slow path re-confirms; cheaper than excluding three indices
       }
-      // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
-      slow = saturated || (p.k4 != kNoKey && key_bound(p.k4) <= bound);
-      if (slow) { g1 = g2 = -1; }             // the slow path re-confirms; cheaper than excluding three indices
-    }
 #endif
 #ifndef SRH_ABL_NORESWEEP
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(slow);
-    while (todo) {                            // wave-uniform loop over the lanes whose pixel needs the slow path
-      const int src = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      double st;
-      int si;
-      if (pretest) slow_pixel<true, TCH>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
-      else slow_pixel<false, TCH>(F, tile, lane, src, (float)c, (float)r, len, bound, g1, g2, d, st, si);
-      if (lane == src && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
-        best = st;
-        besti = si;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(slow);
+      while (todo) {                          // wave-uniform loop over the lanes whose pixel needs the slow path
+        const int sl = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        double st;
+        int si;
+        if (pretest) slow_pixel<true, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        else slow_pixel<false, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        if (lane == sl && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
+          best = st;
+          besti = si;
+        }
       }
-    }
 #endif
-    if (besti == 0x7fffffff) besti = 0;       // nothing hit: np.argmin of an all-inf column
-    float rgb[3], aux[6];
-    const bool want_aux = F.normal_out || F.pos_out;
+      if (live) {
+        if (besti == 0x7fffffff) besti = 0;   // nothing hit: np.argmin of an all-inf column
+        float rgb[3], aux[6];
 #ifdef SRH_ABL_NOSHADE
-    rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __uint_as_float(p.k1);
+        rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __uint_as_float(p.k1);
 #else
-    shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr);
+        shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr);
 #endif
-    if (row_live && c0 + j < F.W) {
-      float* px = image + row * F.img_stride + 3 * (size_t)(c0 + j);
-      px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
-      depth[row * F.depth_stride + (c0 + j)] = background_depth(F, best);
-      if (want_aux) store_aux(F, row, c0 + j, aux);
-#ifdef SRH_DIAG_AGAIN   // diagnostic build: did this pixel take the slow path (1 = nothing confirmed yet, 2 = third bound)
-      if (nearest) nearest[row * F.near_stride + (c0 + j)] = !slow ? 0 : (bound == __builtin_inff() ? 1 : 2);
+        const size_t row = (size_t)(r - F.row0);
+        float* px = image + row * F.img_stride + 3 * (size_t)c;
+        px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
+        depth[row * F.depth_stride + c] = background_depth(F, best);
+        if (want_aux) store_aux(F, row, c, aux);
+#ifdef SRH_DIAG_AGAIN   // diagnostic build: did this pixel take the slow path
+        if (nearest) nearest[row * F.near_stride + c] = slow ? 1 : 0;
 #else
-      if (nearest) nearest[row * F.near_stride + (c0 + j)] = besti;
+        if (nearest) nearest[row * F.near_stride + c] = besti;
 #endif
+      }
     }
   }
 }
