@@ -542,8 +542,9 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {
-    if (F.shading) hipLaunchKernelGGL(k_render_binned<true>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
-    else hipLaunchKernelGGL(k_render_binned<false>, dim3((F.ntiles + 3) / 4), dim3(256), 0, st, F, image, depth, nearest);
+    const unsigned groups = binned_grid(F);   // whole regions of tiles, a multiple of 8 of them (see k_render_binned)
+    if (F.shading) hipLaunchKernelGGL(k_render_binned<true>, dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+    else hipLaunchKernelGGL(k_render_binned<false>, dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);

@@ -440,6 +440,32 @@ struct alignas(16) Parked {
   uint32_t k1, k2, k3, k4;
 };
 
+// Workgroup -> tiles.  A workgroup renders 4 tiles that are neighbours in x (one per wave).  Workgroups are dealt to
+// the 8 XCDs round-robin by the hardware, and each XCD has its own L2; a primitive overlaps neighbouring tiles, so
+// the image is cut into REGIONS of kRegionW x kRegionH workgroups and whole regions are dealt to the XCDs in turn:
+// a primitive's records are then fetched into one or two L2s instead of all eight.  The regions are small and the
+// deal is rotated from one row of regions to the next (no XCD owns a vertical stripe), so every XCD gets an equal
+// share of the busy parts of the image -- measured at 2048^2 x 100k discs: linear order 188 us, 128 x 64-pixel regions
+// 152 us, unrotated 256-pixel stripes 190 us.
+#ifndef SRH_REGION_W
+#define SRH_REGION_W 2
+#endif
+#ifndef SRH_REGION_H
+#define SRH_REGION_H 4
+#endif
+constexpr unsigned kRegionW = SRH_REGION_W, kRegionH = SRH_REGION_H;
+
+__host__ __device__ inline unsigned binned_regions_x(const FrameDev& F) {
+  return (((unsigned)F.tiles_x + 3u) / 4u + kRegionW - 1u) / kRegionW;
+}
+
+// grid size: whole regions, rounded up to a multiple of 8 regions
+__host__ inline unsigned binned_grid(const FrameDev& F) {
+  const unsigned tiles_y = (unsigned)F.tiles_y;
+  const unsigned regions = binned_regions_x(F) * ((tiles_y + kRegionH - 1u) / kRegionH);
+  return ((regions + 7u) & ~7u) * (kRegionW * kRegionH);
+}
+
 // inclusive prefix sum of one int per lane across the wave
 __device__ __forceinline__ int wave_prefix_incl(int v, int lane) {
 #pragma unroll
@@ -471,9 +497,18 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
   __shared__ uint8_t queue[4][256];           // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= F.ntiles) return;               // waves are independent: no block barrier below, LDS slices are per wave
-  const int tx = tile % F.tiles_x, ty = tile / F.tiles_x;
+  int tx, ty;
+  {
+    const unsigned idx = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const unsigned q = idx / (kRegionW * kRegionH), within = idx % (kRegionW * kRegionH);
+    const unsigned nrx = binned_regions_x(F);
+    const unsigned region = q * 8u + ((xcd + 3u * ((q * 8u) / nrx)) & 7u);   // rotate the deal from one region row to the next
+    const unsigned rx = region % nrx, ry = region / nrx;
+    tx = (int)((rx * kRegionW + within % kRegionW) * 4u) + wave;
+    ty = (int)(ry * kRegionH + within / kRegionW);
+  }
+  if (tx >= F.tiles_x || ty >= F.tiles_y) return;              // waves are independent: no block barrier below
+  const int tile = ty * F.tiles_x + tx;
   const int px0 = tx * kTile, py0 = F.row0 + ty * kTile;
   const int c0 = px0 + 4 * (lane & 3);
   const int r_raw = py0 + (lane >> 2);
