@@ -58,8 +58,9 @@ __device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const
   for (int ty = ty0; ty <= ty1; ++ty)
     for (int tx = tx0; tx <= tx1; ++tx, ++k) {
       const double pc0 = tx * kTile, pr0 = F.row0 + ty * kTile;
-      if (shape_reaches_rect(type, rec32, pc0, fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr0,
-                             fmin(pr0 + kTile - 1, (double)(F.row1 - 1)))) {
+      const double pc1 = fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr1 = fmin(pr0 + kTile - 1, (double)(F.row1 - 1));
+      if (shape_reaches_rect(type, rec32, pc0, pc1, pr0, pr1) &&
+          !(F.near_clip > 0.0 && plane_behind_rect(type, rec32, pc0, pc1, pr0, pr1))) {
         mask |= 1ull << k;
         atomicAdd(&count[ty * F.tiles_x + tx], 1u);
       }
@@ -138,9 +139,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
 // tie: the output equals the all-pairs fp64 mode bit for bit.
 // Per pixel the sweep keeps the four smallest KEYS.  A key packs a candidate's depth lower bound and its
 // position in the tile's lists into one 32-bit word so that tracking is four integer min/median operations:
-//   key = (bits(lo) & ~0xFFF) | ordinal      lo > 0 finite: its bit pattern orders like the value, and clearing
+//   key = (bits(lo) & ~0xFFF) | ordinal      lo >= 0 finite: its bit pattern orders like the value, and clearing
 //                                            the low 12 mantissa bits only lowers it -- still a lower bound
-//   key = ordinal                            candidate without a usable bound ("bound 0": confirmed directly)
+//                                            (lo = 0, "no usable bound", gives key = ordinal: confirmed first)
 //   key = 0xFFFFFFFF                         not a candidate
 // ordinal = index of the primitive in the concatenation of the tile's lists, saturated at 4095 (a pixel whose
 // front keys carry the saturated ordinal takes the slow path).
@@ -154,9 +155,19 @@ struct QuadState {
   uint32_t k1[4], k2[4], k3[4], k4[4];   // four smallest keys, ascending
 };
 
-// median of three (LLVM folds this pattern into one v_med3_u32)
+// median of three.  Spelled as max(min(a,b), min(max(a,b),c)) hipcc shares min(a,b) with the neighbouring key update and
+// ends up with four min/max per key instead of one v_med3_u32, so the instruction is named.
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-  return max(min(a, b), min(max(a, b), c));
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// (bits(lo) & ~kOrdMask) | ord in one v_bfi_b32 (ord <= kOrdMask, in a vector register)
+__device__ __forceinline__ uint32_t pack_key(float lo, uint32_t ord) {
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFF000u), "v"(lo), "v"(ord));
+  return r;
 }
 
 __device__ __forceinline__ float key_bound(uint32_t key) { return __uint_as_float(key & ~kOrdMask); }
@@ -195,15 +206,14 @@ struct RejectRecord {
 };
 
 // N pixels of one row (columns cf[0..N-1], row rf, direction lengths len[]) against one reject record:
-//   cand[j]   passes the screen-space reject and has a trusted depth lower bound lo[j] (> 0)
-//   loose[j]  passes the reject but has no usable bound (grazing plane, sphere, near <= 0): must be confirmed
-// A pair that is neither is provably not a valid hit.
+//   cand[j]   passes the screen-space reject; lo[j] >= 0 is then a lower bound of the ray distance of a valid hit
+//             (0 = no usable bound: sphere, near <= 0, withdrawn estimate -- such a candidate ranks first)
+// A pair that is not a candidate is provably not a valid hit.
 template <int TYPE, bool PRETEST, int N>
 __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const float (&cf)[N], float rf,
-                                            const float (&len)[N], bool (&cand)[N], bool (&loose)[N],
-                                            float (&lo)[N]) {
+                                            const float (&len)[N], bool (&cand)[N], float (&lo)[N]) {
   float den[N];
-  float kk = 0.0f, lo_den = 0.0f, hi_den = 0.0f;
+  float lo_u = 0.0f;
   if (TYPE == SRH_PRIM_DISK || TYPE == SRH_PRIM_SPHERE) {
     float q[N];
     ellipse_reject<N>(R.v, cf, rf, q);
@@ -213,7 +223,7 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
       const float rowden = __builtin_fmaf(R[7], rf, R[5]);
 #pragma unroll
       for (int j = 0; j < N; ++j) den[j] = __builtin_fmaf(R[6], cf[j], rowden);
-      kk = R[8]; lo_den = R[9]; hi_den = R[10];
+      lo_u = R[9];
     }
   } else if (TYPE == SRH_PRIM_TRIANGLE) {
     const float r0 = __builtin_fmaf(R[1], rf, R[2]);
@@ -228,39 +238,30 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
       cand[j] = fminf(fminf(e0, e1), e2) >= 0.0f;
       den[j] = __builtin_fmaf(R[7], cf[j], rowden);
     }
-    kk = R[12]; lo_den = R[13]; hi_den = R[14];
+    lo_u = R[13];
   } else {
     const float rowden = __builtin_fmaf(R[2], rf, R[0]);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      cand[j] = true;
       den[j] = __builtin_fmaf(R[1], cf[j], rowden);
+      cand[j] = !PRETEST || den[j] > R[5];    // with near > 0 a plane behind the eye is never a valid hit
     }
-    kk = R[3]; lo_den = R[4]; hi_den = R[5];
-  }
-  if (!PRETEST || TYPE == SRH_PRIM_SPHERE) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) { loose[j] = cand[j]; cand[j] = false; lo[j] = 0.0f; }
-    return;
+    lo_u = R[4];
   }
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    lo[j] = (kk * len[j]) * __builtin_amdgcn_rcpf(den[j]);
-    loose[j] = cand[j] && den[j] < lo_den && den[j] > hi_den;
-    cand[j] = cand[j] && den[j] >= lo_den;
-  }
+  for (int j = 0; j < N; ++j)
+    lo[j] = (!PRETEST || TYPE == SRH_PRIM_SPHERE) ? 0.0f : len[j] * __builtin_amdgcn_rcpf(fmaxf(den[j], lo_u));
 }
 
 // One staged primitive against the lane's four pixels: update the keys.
 template <int TYPE, bool PRETEST>
 __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_t ord, QuadState& Q) {
-  bool cand[4], loose[4];
+  bool cand[4];
   float lo[4];
-  pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, loose, lo);
+  pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, lo);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t ranked = (__float_as_uint(lo[j]) & ~kOrdMask) | ord;
-    const uint32_t key = loose[j] ? ord : (cand[j] ? ranked : kNoKey);
+    const uint32_t key = cand[j] ? pack_key(lo[j], ord) : kNoKey;
     Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
     Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
@@ -279,19 +280,28 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
   RejectRecord<TYPE> A, B;
   const float* base = S.rec32;
   const int first = S.first;
-  int gA = (int)list[0];
-  int gB = (int)list[n > 1 ? 1 : 0];
+#if defined(SRH_ABL_SEQREC)     // timing experiment (wrong results): records read sequentially, no list indirection
+  const uint32_t seq0 = (uint32_t)(((size_t)list >> 2) % (size_t)max(S.count - (int)n, 1));
+  auto entry = [&](uint32_t k) { return first + (int)(seq0 + min(k, n - 1)); };
+#elif defined(SRH_ABL_SAMEREC)  // timing experiment (wrong results): every entry reads the list's first record
+  const int g0 = (int)list[0];
+  auto entry = [&](uint32_t k) { return g0 + 0 * (int)list[min(k, n - 1)]; };
+#else
+  auto entry = [&](uint32_t k) { return (int)list[min(k, n - 1)]; };
+#endif
+  int gA = entry(0);
+  int gB = entry(1);
   A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
   for (uint32_t i = 0; i < n; i += 2) {
     // B <- entry i+1 (clamped: reloading a valid record is harmless), then the list word of entry i+2
     B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
-    gA = (int)list[min(i + 2, n - 1)];
+    gA = entry(i + 2);
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
     sweep_entry<TYPE, PRETEST>(A, min(ord0 + i, kOrdMask), Q);
     if (i + 1 >= n) break;
     __builtin_amdgcn_sched_barrier(0);
     A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
-    gB = (int)list[min(i + 3, n - 1)];
+    gB = entry(i + 3);
     __builtin_amdgcn_sched_barrier(0);
     sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 1, kOrdMask), Q);
     __builtin_amdgcn_sched_barrier(0);
@@ -317,10 +327,10 @@ __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, co
     const int g = (int)list[i];
     RejectRecord<TYPE> R;
     R.load(S.rec32 + (size_t)(g - S.first) * kRec32Stride[TYPE]);
-    bool cand[1], loose[1];
+    bool cand[1];
     float lo[1];
-    pair_bounds<TYPE, PRETEST, 1>(R, P.cf, P.rf, P.len, cand, loose, lo);
-    if ((loose[0] || (cand[0] && lo[0] <= P.bound)) && g != P.g1 && g != P.g2) confirm_global<TCH>(F, g, d, best, besti);
+    pair_bounds<TYPE, PRETEST, 1>(R, P.cf, P.rf, P.len, cand, lo);
+    if (cand[0] && lo[0] <= P.bound && g != P.g1 && g != P.g2) confirm_global<TCH>(F, g, d, best, besti);
   }
 }
 

@@ -18,11 +18,11 @@
 //                  (A = 0: "always a candidate" -- the disc's image is not an ellipse, etc.)
 //                  elongated ellipses use [2] ex [3] ey [4] iu [11] iv > 0: candidate iff
 //                  (u*iu)^2 + (v*iv)^2 - 1 <= 0,  u = ex*dc + ey*dr, v = ex*dr - ey*dc
-//                  [5..7] w0 w1 w2 [8] kk [9] lo_den [10] hi_den : depth estimate, see plane_estimate_record
+//                  [5..7] u0 u1 u2 [9] lo_u [10] hi_u : depth estimate, see plane_estimate_record
 //   sphere (12)    [0..4] as the disc, rest unused
 //   triangle (16)  {a_i, b_i, g_i} at [4i..4i+2], i < 3: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
-//                  [3] w0 [7] w1 [11] w2 [12] kk [13] lo_den [14] hi_den
-//   plane (8)      [0..2] w0 w1 w2 [3] kk [4] lo_den [5] hi_den; every pixel is a candidate
+//                  [3] u0 [7] u1 [11] u2 [13] lo_u [14] hi_u
+//   plane (8)      [0..2] u0 u1 u2 [4] lo_u [5] hi_u; candidate iff den > hi_u
 //
 // Depth estimate of a planar primitive (disc, triangle, plane): the ray distance is
 //   t = k |D| / (n^.D),   n^.D = v0 + c*v1 + r*v2   with v_j = n^.{D0, Dc, Dr}   (affine in the pixel coordinates)
@@ -52,30 +52,36 @@ __device__ inline void rec_zero(float* out, int n) {
 }
 
 // Depth-estimate fields of a planar primitive with unit normal n and plane offset k (see the file header):
-//   w0 = s v0 + E, w1 = s v1, w2 = s v2 with s = sign(k), kk = |k| (1 - 2^-20), lo_den, hi_den.
-// The kernel evaluates den = w0 + c w1 + r w2 = s (n^.D) + E up to an fp32 error below E, where
+//   u_j = w_j / K  with  w0 = s v0 + E, w1 = s v1, w2 = s v2,  s = sign(k),  K = |k| (1 - 2^-20),  and lo_u, hi_u.
+// The kernel evaluates den = u0 + c u1 + r u2 = (s (n^.D) + E) / K up to an fp32 error below E / K, where
 //   E = 2^-21 (|v0| + W |v1| + H |v2|)  covers the three rounded coefficients and the two fmas (2.7x slack),
-// so 0 < s (n^.D) <= den whenever den >= lo_den = 1025 E, and then  t = |k| |D| / (s n^.D) >= kk |D| / den
-// (the 2^-20 absorbs the roundings of kk, |D|, the reciprocal and the two products).
-//   den >= lo_den          trusted: lower bound = kk |D| rcp(den); the sign is right, so t > 0
-//   hi_den < den < lo_den  grazing: no usable bound, the pair must be confirmed
-//   den <= hi_den = -1023 E   provably t < 0: never a valid hit when near > 0
+// so s (n^.D) / K <= den always.  A valid hit with near > 0 has s (n^.D) > 0 and ray distance
+//   t = |k| |D| / (s n^.D) >= |D| / ((1 - 2^-20) max(den, lo_u))      for ANY lo_u > 0
+// (the 2^-20 absorbs the roundings of |D|, the reciprocal and the product).  The kernel uses exactly that,
+//   lower bound = |D| rcp(max(den, lo_u)),   lo_u = 1025 E / K:
+// clamping at lo_u keeps the bound finite and positive where the plane is seen edge-on (it is then simply weak).
+//   den <= hi_u = -1023 E / K   provably t < 0: never a valid hit when near > 0 (used to cull tiles, and per pixel
+//                               for planes, whose every pixel is otherwise a candidate)
+// An estimate that cannot be represented (plane through the eye, overflow) is WITHDRAWN: u = 0 and lo_u = 3e38
+// make the bound 0 everywhere, which ranks the candidate first -- it is then confirmed, not trusted.
 __device__ inline void plane_estimate_record(const double n[3], double k, const PixelBasis& B, int W, int H,
-                                             float* w0, float* w1, float* w2, float* kk, float* lo_den,
-                                             float* hi_den) {
+                                             float* u0, float* u1, float* u2, float* unused, float* lo_u,
+                                             float* hi_u) {
   const double a = dot3(n, B.D0), b = dot3(n, B.Dc), c = dot3(n, B.Dr);
   const double sg = (k > 0.0) ? 1.0 : ((k < 0.0) ? -1.0 : 0.0);
-  double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H);
-  if (!isfinite(e) || !isfinite(k) || !(e < 1.0e30) || !(fabs(k) < 1.0e30)) {
-    *w0 = *w1 = *w2 = *kk = 0.0f;      // den = 0 everywhere: always "grazing", every candidate is confirmed
-    *lo_den = 1.0f;
-    *hi_den = -1.0f;
+  const double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H);
+  const double K = fabs(k) * (1.0 - 9.5367431640625e-7);
+  const double big = (fabs(a) + e + fabs(b) * W + fabs(c) * H) / K, lo = 1025.0 * e / K;
+  *unused = 0.0f;
+  if (!(K > 0.0) || !isfinite(big) || !(big < 1.0e30) || !(lo > 1.0e-30)) {
+    *u0 = *u1 = *u2 = 0.0f;
+    *lo_u = 3.0e38f;
+    *hi_u = -3.0e38f;
     return;
   }
-  *w0 = (float)(sg * a + e); *w1 = (float)(sg * b); *w2 = (float)(sg * c);
-  *kk = (float)(fabs(k) * (1.0 - 9.5367431640625e-7));
-  *lo_den = (float)(1025.0 * e) * 1.0000002f;
-  *hi_den = (float)(-1023.0 * e) * 1.0000002f;
+  *u0 = (float)((sg * a + e) / K); *u1 = (float)(sg * b / K); *u2 = (float)(sg * c / K);
+  *lo_u = (float)lo * 1.0000002f;
+  *hi_u = (float)(-1023.0 * e / K) * 1.0000002f;
 }
 
 // Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4], out[11].
@@ -170,8 +176,8 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
-  // withdraw the estimate (every den counts as grazing) so such candidates are confirmed instead of ranked.
-  if (degenerate) { out[9] = 3.0e38f; out[10] = -3.0e38f; }
+  // withdraw the estimate (bound 0) so such candidates are confirmed instead of ranked.
+  if (degenerate) { out[5] = out[6] = out[7] = 0.0f; out[9] = 3.0e38f; out[10] = -3.0e38f; }
 }
 
 // sphere: the ray's line meets it iff (oc.D)^2 - |D|^2 (|oc|^2 - r^2) >= 0   (numpy/renderer.py:20-25).
@@ -295,6 +301,16 @@ __device__ inline BBox triangle_bbox(const float* rec) {
     cmin = fmin(cmin, c); cmax = fmax(cmax, c); rmin = fmin(rmin, r); rmax = fmax(rmax, r);
   }
   return BBox{cmin - 1.0, cmax + 1.0, rmin - 1.0, rmax + 1.0, false};
+}
+
+// Is the primitive's plane provably behind the eye (t < 0) for every pixel of the rectangle?  den is affine, so its
+// maximum sits at a corner; evaluated in fp64 on the stored coefficients it is >= the true scaled s (n^.D).
+__device__ inline bool plane_behind_rect(int type, const float* rec, double c0, double c1, double r0, double r1) {
+  double u0, u1, u2, hi;
+  if (type == SRH_PRIM_DISK) { u0 = rec[5]; u1 = rec[6]; u2 = rec[7]; hi = rec[10]; }
+  else if (type == SRH_PRIM_TRIANGLE) { u0 = rec[3]; u1 = rec[7]; u2 = rec[11]; hi = rec[14]; }
+  else return false;
+  return u0 + fmax(u1 * c0, u1 * c1) + fmax(u2 * r0, u2 * r1) <= hi;
 }
 
 // Does the stored reject shape reach the pixel rectangle [c0,c1] x [r0,r1] (inclusive pixel coordinates)?  Used to drop
