@@ -261,7 +261,8 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
   pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, lo);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t key = cand[j] ? pack_key(lo[j], ord) : kNoKey;
+    const uint32_t ranked = pack_key(lo[j], ord);   // unconditionally: an asm in a ?: arm would become a branch
+    const uint32_t key = cand[j] ? ranked : kNoKey;
     Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
     Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
