@@ -1,7 +1,8 @@
 // BINNED mode kernels (gfx950): screen-space tile binning + one WAVE per 16x16-pixel tile.
 //
-//   k_prep (srh.hip)   also writes each primitive's tile range and either counts it into the bins it
-//                      overlaps (atomicAdd on per-bin counters) or appends it to its batch's `large` list
+//   k_prep (srh.hip)   also writes each primitive's box of tiles, or appends it to its batch's `large` list
+//   k_bin_count        per primitive and tile of its box: does the reject shape reach the tile?  If so count the
+//                      primitive into that bin (atomicAdd on per-bin counters) and set the tile's bit in its mask
 //   k_bin_scan         exclusive prefix sum of the per-bin counts (one workgroup)
 //   k_bin_fill         second pass over the primitives: claim a slot per overlapped bin, write the index
 //   k_render_binned    per tile: sweep the tile's primitives, confirm the front one per pixel, shade, store
@@ -51,21 +52,54 @@ __device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const
     return;
   }
   tr[0] = (uint16_t)tx0; tr[1] = (uint16_t)ty0; tr[2] = (uint16_t)tx1; tr[3] = (uint16_t)ty1;
-  // of the (at most 64) tiles of the box keep those the shape really reaches; bit k = k-th tile, row-major
+}
+
+__device__ __forceinline__ int rec32_stride(int type) {
+  return type == SRH_PRIM_DISK ? kRec32Stride[0] : type == SRH_PRIM_PLANE ? kRec32Stride[1]
+       : type == SRH_PRIM_SPHERE ? kRec32Stride[2] : kRec32Stride[3];
+}
+
+#ifndef SRH_COUNT_LANES
+#define SRH_COUNT_LANES 2
+#endif
+constexpr int kCountLanes = SRH_COUNT_LANES;
+
+// ---- count: kCountLanes lanes per primitive, one tile of its box per lane and step ------------------------------
+// Of the (at most 64) tiles of the box keep those the reject shape really reaches and that are not provably behind
+// the eye; bit k of the primitive's tile mask = k-th tile of the box, row-major.  k_prep leaves this to a kernel of
+// its own because a thread per primitive walking up to 64 tiles in fp64 is a long serial chain on a launch that
+// has only a wave or two per SIMD.
+__global__ __launch_bounds__(256) void k_bin_count(FrameDev F) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gidx = t / kCountLanes, sub = t % kCountLanes;
+  if (gidx >= F.total) return;                                  // whole lane groups leave together
+  const uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
+  const int tx0 = tr[0], ty0 = tr[1], tx1 = tr[2], ty1 = tr[3];
+  if (tx0 > tx1) return;
+  const int seg = segment_of(F, gidx);
+  int type = F.seg[0].type, first = F.seg[0].first;
+  const float* base = F.seg[0].rec32;
+#pragma unroll
+  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+    if (seg == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec32; }
+  const float* rec32 = base + (size_t)(gidx - first) * rec32_stride(type);
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
+  const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+  const RectTest T(type, rec32, F.near_clip > 0.0);
   uint64_t mask = 0;
-  int k = 0;
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx, ++k) {
-      const double pc0 = tx * kTile, pr0 = F.row0 + ty * kTile;
-      const double pc1 = fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr1 = fmin(pr0 + kTile - 1, (double)(F.row1 - 1));
-      if (shape_reaches_rect(type, rec32, pc0, pc1, pr0, pr1) &&
-          !(F.near_clip > 0.0 && plane_behind_rect(type, rec32, pc0, pc1, pr0, pr1))) {
-        mask |= 1ull << k;
-        atomicAdd(&count[ty * F.tiles_x + tx], 1u);
-      }
+  for (int k = sub; k < n; k += kCountLanes) {
+    const int tx = tx0 + k % nx, ty = ty0 + k / nx;
+    const double pc0 = tx * kTile, pr0 = F.row0 + ty * kTile;
+    const double pc1 = fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr1 = fmin(pr0 + kTile - 1, (double)(F.row1 - 1));
+    if (T.reaches(pc0, pc1, pr0, pr1)) {
+      mask |= 1ull << k;
+      atomicAdd(&count[ty * F.tiles_x + tx], 1u);
     }
-  F.tilemask[gidx] = mask;
+  }
+  uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+#pragma unroll
+  for (int m = 1; m < kCountLanes; m <<= 1) { lo |= __shfl_xor(lo, m); hi |= __shfl_xor(hi, m); }
+  if (sub == 0) F.tilemask[gidx] = ((uint64_t)hi << 32) | lo;
 }
 
 // ---- exclusive scan of the bin counts: one 1024-thread workgroup, 16-byte loads ---------------------------

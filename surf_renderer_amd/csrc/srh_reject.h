@@ -303,54 +303,65 @@ __device__ inline BBox triangle_bbox(const float* rec) {
   return BBox{cmin - 1.0, cmax + 1.0, rmin - 1.0, rmax + 1.0, false};
 }
 
-// Is the primitive's plane provably behind the eye (t < 0) for every pixel of the rectangle?  den is affine, so its
-// maximum sits at a corner; evaluated in fp64 on the stored coefficients it is >= the true scaled s (n^.D).
-__device__ inline bool plane_behind_rect(int type, const float* rec, double c0, double c1, double r0, double r1) {
-  double u0, u1, u2, hi;
-  if (type == SRH_PRIM_DISK) { u0 = rec[5]; u1 = rec[6]; u2 = rec[7]; hi = rec[10]; }
-  else if (type == SRH_PRIM_TRIANGLE) { u0 = rec[3]; u1 = rec[7]; u2 = rec[11]; hi = rec[14]; }
-  else return false;
-  return u0 + fmax(u1 * c0, u1 * c1) + fmax(u2 * r0, u2 * r1) <= hi;
-}
+// Can a pixel of the rectangle [c0,c1] x [r0,r1] (inclusive pixel coordinates) be a valid hit of the primitive whose
+// reject record this is?  Used to drop tiles of a primitive's box that it cannot reach (box corners of round or
+// slanted shapes, tiles where its plane is behind the eye).  Two proofs of "no":
+//   shape   true hits lie inside the stored (inflated) reject shape, so the exact fp64 minimum of the stored
+//           ellipse form over the rectangle being > 1, or one stored triangle edge function being negative at all
+//           four corners, rules the rectangle out;
+//   plane   den is affine, so its maximum sits at a corner; evaluated in fp64 on the stored coefficients it is
+//           >= the true scaled s (n^.D), and a value <= hi_u means t < 0 everywhere (only used when near > 0).
+struct RectTest {
+  int type;
+  bool ellipse, behind;
+  double x0, y0, A11, A12, A22, i11, i22;       // ellipse centre, quadratic form, 1 / A11, 1 / A22
+  double ea[3], eb[3], eg[3];                   // triangle edge functions
+  double u0, u1, u2, hi;                        // depth-estimate denominator
 
-// Does the stored reject shape reach the pixel rectangle [c0,c1] x [r0,r1] (inclusive pixel coordinates)?  Used to drop
-// tiles of a primitive's bounding box that its shape misses (box corners of round or slanted shapes).  A tile may
-// be dropped only if no pixel in it can be a true hit; true hits lie inside the stored (inflated) shape, so the
-// exact fp64 minimum of the stored form over the rectangle being > 1 (ellipse), or one stored edge function being
-// negative at all four corners (triangle), proves that.
-__device__ inline bool shape_reaches_rect(int type, const float* rec, double c0, double c1, double r0, double r1) {
-  if (type == SRH_PRIM_TRIANGLE) {
-    for (int i = 0; i < 3; ++i) {
-      const double a = rec[4 * i], b = rec[4 * i + 1], g = rec[4 * i + 2];
-      if (a * (a > 0.0 ? c1 : c0) + b * (b > 0.0 ? r1 : r0) + g < 0.0) return false;
+  __device__ inline RectTest(int type_, const float* rec, bool near_positive) : type(type_), ellipse(false), behind(false) {
+    if (type == SRH_PRIM_TRIANGLE) {
+      for (int i = 0; i < 3; ++i) { ea[i] = rec[4 * i]; eb[i] = rec[4 * i + 1]; eg[i] = rec[4 * i + 2]; }
+      u0 = rec[3]; u1 = rec[7]; u2 = rec[11]; hi = rec[14];
+      behind = near_positive;
+    } else if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) {
+      if (rec[11] > 0.0f) {                                    // principal-axes form -> quadratic form
+        const double ex = rec[2], ey = rec[3], iu2 = (double)rec[4] * rec[4], iv2 = (double)rec[11] * rec[11];
+        A11 = ex * ex * iu2 + ey * ey * iv2;
+        A12 = ex * ey * (iu2 - iv2);
+        A22 = ey * ey * iu2 + ex * ex * iv2;
+      } else {
+        A11 = rec[2]; A12 = 0.5 * (double)rec[3]; A22 = rec[4];
+      }
+      ellipse = (A11 > 0.0) && (A22 > 0.0);                    // else "always a candidate"
+      i11 = ellipse ? 1.0 / A11 : 0.0;
+      i22 = ellipse ? 1.0 / A22 : 0.0;
+      x0 = rec[0]; y0 = rec[1];
+      if (type == SRH_PRIM_DISK) { u0 = rec[5]; u1 = rec[6]; u2 = rec[7]; hi = rec[10]; behind = near_positive; }
     }
-    return true;
   }
-  if (type != SRH_PRIM_DISK && type != SRH_PRIM_SPHERE) return true;
-  double A11, A12, A22;
-  if (rec[11] > 0.0f) {                                    // principal-axes form -> quadratic form
-    const double ex = rec[2], ey = rec[3], iu2 = (double)rec[4] * rec[4], iv2 = (double)rec[11] * rec[11];
-    A11 = ex * ex * iu2 + ey * ey * iv2;
-    A12 = ex * ey * (iu2 - iv2);
-    A22 = ey * ey * iu2 + ex * ex * iv2;
-  } else {
-    A11 = rec[2]; A12 = 0.5 * (double)rec[3]; A22 = rec[4];
+
+  __device__ inline bool reaches(double c0, double c1, double r0, double r1) const {
+    if (behind && u0 + fmax(u1 * c0, u1 * c1) + fmax(u2 * r0, u2 * r1) <= hi) return false;
+    if (type == SRH_PRIM_TRIANGLE) {
+      for (int i = 0; i < 3; ++i)
+        if (ea[i] * (ea[i] > 0.0 ? c1 : c0) + eb[i] * (eb[i] > 0.0 ? r1 : r0) + eg[i] < 0.0) return false;
+      return true;
+    }
+    if (!ellipse) return true;
+    if (x0 >= c0 && x0 <= c1 && y0 >= r0 && y0 <= r1) return true;
+    // centre outside: the minimum of the form over the rectangle is on its boundary; per edge the form is a
+    // parabola in the free coordinate, minimised at its clamped vertex
+    double qmin = 1e300;
+    for (int e = 0; e < 2; ++e) {
+      const double dc = (e ? c1 : c0) - x0;
+      const double dr = fmin(fmax(-A12 * dc * i22, r0 - y0), r1 - y0);
+      qmin = fmin(qmin, A11 * dc * dc + 2.0 * A12 * dc * dr + A22 * dr * dr);
+      const double dr2 = (e ? r1 : r0) - y0;
+      const double dc2 = fmin(fmax(-A12 * dr2 * i11, c0 - x0), c1 - x0);
+      qmin = fmin(qmin, A11 * dc2 * dc2 + 2.0 * A12 * dc2 * dr2 + A22 * dr2 * dr2);
+    }
+    return !(qmin > 1.000001);
   }
-  if (!(A11 > 0.0) || !(A22 > 0.0)) return true;           // "always a candidate"
-  const double x0 = (double)rec[0], y0 = (double)rec[1];
-  if (x0 >= c0 && x0 <= c1 && y0 >= r0 && y0 <= r1) return true;
-  auto Q = [&](double dc, double dr) { return A11 * dc * dc + 2.0 * A12 * dc * dr + A22 * dr * dr; };
-  double qmin = 1e300;
-  // vertical edges c = c0, c1: minimise over dr; horizontal edges r = r0, r1: minimise over dc
-  for (int e = 0; e < 2; ++e) {
-    const double dc = (e ? c1 : c0) - x0;
-    const double dr = fmin(fmax(-A12 * dc / A22, r0 - y0), r1 - y0);
-    qmin = fmin(qmin, Q(dc, dr));
-    const double dr2 = (e ? r1 : r0) - y0;
-    const double dc2 = fmin(fmax(-A12 * dr2 / A11, c0 - x0), c1 - x0);
-    qmin = fmin(qmin, Q(dc2, dr2));
-  }
-  return !(qmin > 1.000001);
-}
+};
 
 }  // namespace srh
