@@ -171,40 +171,55 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
 //           the confirmed depth, and merges the results with a wavefront-shuffle lexicographic minimum.
 // A candidate is skipped only when its lower bound exceeds an exactly confirmed depth, so it can neither win nor
 // tie: the output equals the all-pairs fp64 mode bit for bit.
-// Per pixel the sweep keeps the four smallest KEYS.  A key packs a candidate's depth lower bound and its
-// position in the tile's lists into one 32-bit word so that tracking is four integer min/median operations:
-//   key = (bits(lo) & ~0xFFF) | ordinal      lo >= 0 finite: its bit pattern orders like the value, and clearing
-//                                            the low 12 mantissa bits only lowers it -- still a lower bound
-//                                            (lo = 0, "no usable bound", gives key = ordinal: confirmed first)
-//   key = 0xFFFFFFFF                         not a candidate
-// ordinal = index of the primitive in the concatenation of the tile's lists, saturated at 4095 (a pixel whose
-// front keys carry the saturated ordinal takes the slow path).
+// Per pixel the sweep keeps the four LARGEST keys.  A key packs an UPPER bound of a candidate's inverse ray distance
+// and its position in the tile's lists into one 32-bit word, so that tracking is four integer max/median operations
+// and the sweep needs no reciprocal:
+//   inv = den * rlen                         den: affine estimate (plane_estimate_record), rlen = 1 / |D|;
+//                                            inv >= 1 / t for a valid hit, inv <= 0 proves there is none (near > 0)
+//   key = (bits(inv) & ~0xFFF) | field       compared as SIGNED integers: positive floats order like their bit
+//                                            patterns, negative ones are negative and never displace the initial 0.
+//                                            Decoded with the low bits SET, so it is still an upper bound of 1 / t
+//   key = (bits(1e30) & ~0xFFF) | field      candidate without an estimate (sphere, near <= 0, withdrawn): ranks first
+//   key = 0                                  not a candidate
+// field = 1 + index of the primitive in the concatenation of the tile's lists, saturated at 4095 (a pixel whose
+// front keys carry the saturated field takes the slow path).
+// Cost model behind the arithmetic (measured on MI355X, ns per wave instruction and SIMD): v_add/sub/mul_f32,
+// and/or/xor/not, ashr and integer add on VGPRs 1.0; every VOP3, fma, min/max/med3, compares, bfi and the packed
+// f32 forms 1.8 (a packed fma does two pixels); v_rcp_f32 3.5; cmp + cndmask 2.9 against ashr + and 2.1.
 constexpr uint32_t kOrdMask = 0xFFFu;
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr int32_t kNoKey = 0;
+constexpr float kNoEstimate = 1.0e30f;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct QuadState {
-  float cf[4];        // pixel columns as fp32 (exact integers)
+  f32x2 cf[2];        // pixel columns as fp32 (exact integers): (c, c+1), (c+2, c+3)
   float rf;           // pixel row
-  float len[4];       // |D| of the un-normalised ray direction
-  uint32_t k1[4], k2[4], k3[4], k4[4];   // four smallest keys, ascending
+  f32x2 rlen[2];      // 1 / |D| of the un-normalised ray direction
+  int32_t k1[4], k2[4], k3[4], k4[4];   // four largest keys, descending
 };
 
-// median of three.  Spelled as max(min(a,b), min(max(a,b),c)) hipcc shares min(a,b) with the neighbouring key update and
-// ends up with four min/max per key instead of one v_med3_u32, so the instruction is named.
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t r;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+// median of three.  Spelled with min/max hipcc shares a min with the neighbouring key update and ends up with four
+// min/max per key instead of one v_med3_i32, so the instruction is named.
+__device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
+  int32_t r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 
-// (bits(lo) & ~kOrdMask) | ord in one v_bfi_b32 (ord <= kOrdMask, in a vector register)
-__device__ __forceinline__ uint32_t pack_key(float lo, uint32_t ord) {
-  uint32_t r;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFF000u), "v"(lo), "v"(ord));
+// (bits(inv) & ~kOrdMask) | field in one v_bfi_b32 (field <= kOrdMask, in a vector register)
+__device__ __forceinline__ int32_t pack_key(float inv, uint32_t field) {
+  int32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFF000u), "v"(inv), "v"(field));
   return r;
 }
 
-__device__ __forceinline__ float key_bound(uint32_t key) { return __uint_as_float(key & ~kOrdMask); }
+__device__ __forceinline__ bool key_saturated(int32_t key) { return ((uint32_t)key & kOrdMask) == kOrdMask; }
+__device__ __forceinline__ uint32_t key_ordinal(int32_t key) { return ((uint32_t)key & kOrdMask) - 1u; }
+
+// fp32 LOWER bound of the ray distance a key stands for (rcp is good to 1 ulp; the factor covers it)
+__device__ __forceinline__ float inv_to_bound(float inv_upper) { return __builtin_amdgcn_rcpf(inv_upper) * 0.9999995f; }
+__device__ __forceinline__ float key_bound(int32_t key) { return inv_to_bound(__uint_as_float((uint32_t)key | kOrdMask)); }
 
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
 __device__ __forceinline__ float float_above(double t) { return (float)t * 1.0000005f; }
@@ -239,72 +254,95 @@ struct RejectRecord {
   __device__ __forceinline__ float operator[](int i) const { return v[i]; }
 };
 
-// N pixels of one row (columns cf[0..N-1], row rf, direction lengths len[]) against one reject record:
-//   cand[j]   passes the screen-space reject; lo[j] >= 0 is then a lower bound of the ray distance of a valid hit
-//             (0 = no usable bound: sphere, near <= 0, withdrawn estimate -- such a candidate ranks first)
-// A pair that is not a candidate is provably not a valid hit.
-template <int TYPE, bool PRETEST, int N>
-__device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const float (&cf)[N], float rf,
-                                            const float (&len)[N], bool (&cand)[N], float (&lo)[N]) {
-  float den[N];
-  float lo_u = 0.0f;
+// The lane's four pixels (one row: columns cf, row rf, inverse direction lengths rlen) against one reject record:
+//   sel[j]   all ones if pixel j passes the screen-space reject, else 0
+//   inv[j]   upper bound of 1 / t of a valid hit (kNoEstimate: no usable bound; <= 0: provably no valid hit)
+// A pair that does not pass is provably not a valid hit.  Written on two-pixel vectors so that hipcc emits the
+// packed f32 forms; the selects are sign masks (v_ashrrev_i32) instead of compare + select.
+__device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int TYPE, bool PRETEST>
+__device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f32x2 (&cf)[2], float rf,
+                                            const f32x2 (&rlen)[2], int32_t (&sel)[4], f32x2 (&inv)[2]) {
+  f32x2 den[2];
   if (TYPE == SRH_PRIM_DISK || TYPE == SRH_PRIM_SPHERE) {
-    float q[N];
-    ellipse_reject<N>(R.v, cf, rf, q);
+    // candidate iff q <= 0; tested as q - 2^-22 < 0 (a superset) so that the sign bit decides
+    const float dr = rf - R[1];
+    f32x2 q[2];
+    if (R[11] > 0.0f) {                                     // principal-axes form (wave-uniform branch)
+      const float eydr = R[3] * dr, exdr = R[2] * dr;
 #pragma unroll
-    for (int j = 0; j < N; ++j) cand[j] = q[j] <= 0.0f;
+      for (int p = 0; p < 2; ++p) {
+        const f32x2 dc = cf[p] - splat2(R[0]);
+        const f32x2 u = fma2(splat2(R[2]), dc, splat2(eydr)) * splat2(R[4]);
+        const f32x2 v = fma2(splat2(-R[3]), dc, splat2(exdr)) * splat2(R[11]);
+        q[p] = fma2(u, u, fma2(v, v, splat2(-1.00000024f)));
+      }
+    } else {
+      const float ee = R[3] * dr;
+      const float gg = __builtin_fmaf(R[4] * dr, dr, -1.00000024f);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const f32x2 dc = cf[p] - splat2(R[0]);
+        q[p] = fma2(dc, fma2(splat2(R[2]), dc, splat2(ee)), splat2(gg));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sel[j] = __float_as_int(q[j >> 1][j & 1]) >> 31;
     if (TYPE == SRH_PRIM_DISK) {
       const float rowden = __builtin_fmaf(R[7], rf, R[5]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) den[j] = __builtin_fmaf(R[6], cf[j], rowden);
-      lo_u = R[9];
+      for (int p = 0; p < 2; ++p) den[p] = fma2(splat2(R[6]), cf[p], splat2(rowden));
     }
   } else if (TYPE == SRH_PRIM_TRIANGLE) {
+    // candidate iff all three edge functions are >= 0; a true hit has them > 0 (the margin in g), so the
+    // largest NEGATED one is < 0 and its sign bit decides
     const float r0 = __builtin_fmaf(R[1], rf, R[2]);
     const float r1 = __builtin_fmaf(R[5], rf, R[6]);
     const float r2 = __builtin_fmaf(R[9], rf, R[10]);
     const float rowden = __builtin_fmaf(R[11], rf, R[3]);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float e0 = __builtin_fmaf(R[0], cf[j], r0);
-      const float e1 = __builtin_fmaf(R[4], cf[j], r1);
-      const float e2 = __builtin_fmaf(R[8], cf[j], r2);
-      cand[j] = fminf(fminf(e0, e1), e2) >= 0.0f;
-      den[j] = __builtin_fmaf(R[7], cf[j], rowden);
+    for (int p = 0; p < 2; ++p) {
+      const f32x2 e0 = fma2(splat2(-R[0]), cf[p], splat2(-r0));
+      const f32x2 e1 = fma2(splat2(-R[4]), cf[p], splat2(-r1));
+      const f32x2 e2 = fma2(splat2(-R[8]), cf[p], splat2(-r2));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) sel[2 * p + h] = __float_as_int(fmaxf(fmaxf(e0[h], e1[h]), e2[h])) >> 31;
+      den[p] = fma2(splat2(R[7]), cf[p], splat2(rowden));
     }
-    lo_u = R[13];
   } else {
     const float rowden = __builtin_fmaf(R[2], rf, R[0]);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      den[j] = __builtin_fmaf(R[1], cf[j], rowden);
-      cand[j] = !PRETEST || den[j] > R[5];    // with near > 0 a plane behind the eye is never a valid hit
-    }
-    lo_u = R[4];
+    for (int p = 0; p < 2; ++p) den[p] = fma2(splat2(R[1]), cf[p], splat2(rowden));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sel[j] = -1;                // every pixel; behind the eye inv <= 0 drops out by itself
   }
 #pragma unroll
-  for (int j = 0; j < N; ++j)
-    lo[j] = (!PRETEST || TYPE == SRH_PRIM_SPHERE) ? 0.0f : len[j] * __builtin_amdgcn_rcpf(fmaxf(den[j], lo_u));
+  for (int p = 0; p < 2; ++p) {
+    if (!PRETEST || TYPE == SRH_PRIM_SPHERE) inv[p] = splat2(kNoEstimate);
+    else inv[p] = den[p] * rlen[p];
+  }
 }
 
 // One staged primitive against the lane's four pixels: update the keys.
 template <int TYPE, bool PRETEST>
-__device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_t ord, QuadState& Q) {
-  bool cand[4];
-  float lo[4];
-  pair_bounds<TYPE, PRETEST, 4>(R, Q.cf, Q.rf, Q.len, cand, lo);
+__device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_t field, QuadState& Q) {
+  int32_t sel[4];
+  f32x2 inv[2];
+  pair_bounds<TYPE, PRETEST>(R, Q.cf, Q.rf, Q.rlen, sel, inv);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t ranked = pack_key(lo[j], ord);   // unconditionally: an asm in a ?: arm would become a branch
-    const uint32_t key = cand[j] ? ranked : kNoKey;
-    Q.k4[j] = umed3(Q.k3[j], key, Q.k4[j]);
-    Q.k3[j] = umed3(Q.k2[j], key, Q.k3[j]);
-    Q.k2[j] = umed3(Q.k1[j], key, Q.k2[j]);
-    Q.k1[j] = min(Q.k1[j], key);
+    const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
+    Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
+    Q.k3[j] = imed3(Q.k2[j], key, Q.k3[j]);
+    Q.k2[j] = imed3(Q.k1[j], key, Q.k2[j]);
+    Q.k1[j] = max(Q.k1[j], key);
   }
 }
 
-// The hot loop: fp32 only, straight-line, updates the per-pixel keys.  `ord0` = ordinal of the list's first entry.
+// The hot loop: fp32 only, straight-line, updates the per-pixel keys.  `ord0` = ordinal of the list's first entry
+// (the key field is the ordinal + 1).
 // Scalar loads complete out of order, so the only wait is "all of them": the loop is unrolled by two over two
 // record buffers A and B -- while A is evaluated, B's record (and the list word after it) is in flight, and the
 // wait for B comes only after A's ~100 vector instructions.  No register copies between the buffers.
@@ -332,13 +370,13 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
     B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
     gA = entry(i + 2);
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
-    sweep_entry<TYPE, PRETEST>(A, min(ord0 + i, kOrdMask), Q);
+    sweep_entry<TYPE, PRETEST>(A, min(ord0 + i + 1, kOrdMask), Q);
     if (i + 1 >= n) break;
     __builtin_amdgcn_sched_barrier(0);
     A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
     gB = entry(i + 3);
     __builtin_amdgcn_sched_barrier(0);
-    sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 1, kOrdMask), Q);
+    sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 2, kOrdMask), Q);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -348,7 +386,7 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
 // pixel's confirmed depth; the per-lane results are merged with a lexicographic (t, index) minimum over the wave
 // by cross-lane shuffles.
 struct SlowPixel {
-  float cf[1], len[1];
+  f32x2 cf[2], rlen[2];   // the one pixel, replicated: the slow path reuses the sweep's quad arithmetic
   float rf;
   float bound;        // fp32 value >= the depth confirmed so far
   int g1, g2;         // already confirmed
@@ -362,10 +400,12 @@ __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, co
     const int g = (int)list[i];
     RejectRecord<TYPE> R;
     R.load(S.rec32 + (size_t)(g - S.first) * kRec32Stride[TYPE]);
-    bool cand[1];
-    float lo[1];
-    pair_bounds<TYPE, PRETEST, 1>(R, P.cf, P.rf, P.len, cand, lo);
-    if (cand[0] && lo[0] <= P.bound && g != P.g1 && g != P.g2) confirm_global<TCH>(F, g, d, best, besti);
+    int32_t sel[4];
+    f32x2 inv[2];
+    pair_bounds<TYPE, PRETEST>(R, P.cf, P.rf, P.rlen, sel, inv);
+    const float iv = inv[0][0];
+    if (sel[0] && iv > 0.0f && inv_to_bound(iv * 1.0000005f) <= P.bound && g != P.g1 && g != P.g2)
+      confirm_global<TCH>(F, g, d, best, besti);
   }
 }
 
@@ -443,12 +483,13 @@ __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, ui
 // everything confirmed here (index 0x7fffffff = nothing), valid in every lane.
 template <bool PRETEST, bool TCH>
 __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane, int src, float cf, float rf,
-                                           float len, float bound, int g1, int g2, const double d[3],
+                                           float rlen, float bound, int g1, int g2, const double d[3],
                                            double& out_t, int& out_i) {
   SlowPixel P;
-  P.cf[0] = readlane_f32(cf, src);
+  const float cs = readlane_f32(cf, src), ls = readlane_f32(rlen, src);
+  P.cf[0] = P.cf[1] = f32x2{cs, cs};
+  P.rlen[0] = P.rlen[1] = f32x2{ls, ls};
   P.rf = readlane_f32(rf, src);
-  P.len[0] = readlane_f32(len, src);
   P.bound = readlane_f32(bound, src);
   P.g1 = __builtin_amdgcn_readlane(g1, src);
   P.g2 = __builtin_amdgcn_readlane(g2, src);
@@ -482,7 +523,7 @@ __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane
 
 // per-pixel result of the sweep, parked in LDS between the sweep and the finish phase
 struct alignas(16) Parked {
-  uint32_t k1, k2, k3, k4;
+  int32_t k1, k2, k3, k4;
 };
 
 // Workgroup -> tiles.  A workgroup renders 4 tiles that are neighbours in x (one per wave).  Workgroups are dealt to
@@ -539,6 +580,7 @@ template <bool TCH>
 __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
+  __shared__ int32_t front[4][4][64];         // global index of each pixel's front candidate (-1: none / saturated)
   __shared__ uint8_t queue[4][256];           // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -573,8 +615,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
     for (int j = 0; j < 4; ++j) {
       const int c = min(c0 + j, F.W - 1);
       double dtmp[3];
-      Q.cf[j] = (float)c;
-      Q.len[j] = (float)pixel_ray(F, c, r, dtmp);
+      Q.cf[j >> 1][j & 1] = (float)c;
+      Q.rlen[j >> 1][j & 1] = (float)(1.0 / pixel_ray(F, c, r, dtmp));
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     if (pretest) sweep_tile<true>(F, tile, Q);
@@ -585,6 +627,13 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       p.k1 = Q.k1[j]; p.k2 = Q.k2[j]; p.k3 = Q.k3[j]; p.k4 = Q.k4[j];
       park[wave][j][lane] = p;
       if (p.k1 != kNoKey && row_live && c0 + j < F.W) has |= 1u << j;
+    }
+    // the front keys' list entries, looked up here so that the four loads are in flight together and the finish
+    // rounds start from a global index instead of a dependent list read
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      front[wave][j][lane] =
+          (((has >> j) & 1u) && !key_saturated(Q.k1[j])) ? ordinal_to_global(F, tile, key_ordinal(Q.k1[j])) : -1;
     }
   }
 
@@ -640,8 +689,9 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       const int j = id >> 6, src = id & 63;
       const int c = px0 + 4 * (src & 3) + j, r = py0 + (src >> 2);
       const Parked p = park[wave][j][src];
+      const int gfront = front[wave][j][src];
       double d[3];
-      const float len = (float)pixel_ray(F, c, r, d);
+      const float rlen = (float)(1.0 / pixel_ray(F, c, r, d));
       double best = __builtin_inf();
       int besti = 0x7fffffff;
       float bound = __builtin_inff();
@@ -652,16 +702,16 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
         // Confirm the front candidates in key order while their bound still reaches the confirmed depth (the
         // first one always; the next ones after a near miss at an ellipse edge or for nearly coplanar primitives).
         // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
-        const uint32_t keys[3] = {p.k1, p.k2, p.k3};
+        const int32_t keys[3] = {p.k1, p.k2, p.k3};
         bool saturated = false;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const uint32_t key = keys[q];
+          const int32_t key = keys[q];
           if (key != kNoKey && !saturated && key_bound(key) <= bound) {
-            if ((key & kOrdMask) == kOrdMask) {
+            if (key_saturated(key)) {
               saturated = true;
             } else {
-              const int g = ordinal_to_global(F, tile, key & kOrdMask);
+              const int g = (q == 0) ? gfront : ordinal_to_global(F, tile, key_ordinal(key));
               if (q == 0) g1 = g;
               if (q == 1) g2 = g;
               confirm_global<TCH>(F, g, d, best, besti);
@@ -681,8 +731,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
         todo &= todo - 1;
         double st;
         int si;
-        if (pretest) slow_pixel<true, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
-        else slow_pixel<false, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        if (pretest) slow_pixel<true, TCH>(F, tile, lane, sl, (float)c, (float)r, rlen, bound, g1, g2, d, st, si);
+        else slow_pixel<false, TCH>(F, tile, lane, sl, (float)c, (float)r, rlen, bound, g1, g2, d, st, si);
         if (lane == sl && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
           best = st;
           besti = si;
@@ -693,7 +743,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
         if (besti == 0x7fffffff) besti = 0;   // nothing hit: np.argmin of an all-inf column
         float rgb[3], aux[6];
 #ifdef SRH_ABL_NOSHADE
-        rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __uint_as_float(p.k1);
+        rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __int_as_float(p.k1);
 #else
         shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr);
 #endif

@@ -62,8 +62,9 @@ __device__ inline void rec_zero(float* out, int n) {
 // clamping at lo_u keeps the bound finite and positive where the plane is seen edge-on (it is then simply weak).
 //   den <= hi_u = -1023 E / K   provably t < 0: never a valid hit when near > 0 (used to cull tiles, and per pixel
 //                               for planes, whose every pixel is otherwise a candidate)
-// An estimate that cannot be represented (plane through the eye, overflow) is WITHDRAWN: u = 0 and lo_u = 3e38
-// make the bound 0 everywhere, which ranks the candidate first -- it is then confirmed, not trusted.
+// An estimate that cannot be represented (plane through the eye, overflow) is WITHDRAWN: u0 = 1e30, u1 = u2 = 0
+// make den huge everywhere, i.e. "as near as can be", which ranks the candidate first -- it is then confirmed,
+// not trusted.
 __device__ inline void plane_estimate_record(const double n[3], double k, const PixelBasis& B, int W, int H,
                                              float* u0, float* u1, float* u2, float* unused, float* lo_u,
                                              float* hi_u) {
@@ -74,7 +75,8 @@ __device__ inline void plane_estimate_record(const double n[3], double k, const 
   const double big = (fabs(a) + e + fabs(b) * W + fabs(c) * H) / K, lo = 1025.0 * e / K;
   *unused = 0.0f;
   if (!(K > 0.0) || !isfinite(big) || !(big < 1.0e30) || !(lo > 1.0e-30)) {
-    *u0 = *u1 = *u2 = 0.0f;
+    *u0 = 1.0e30f;
+    *u1 = *u2 = 0.0f;
     *lo_u = 3.0e38f;
     *hi_u = -3.0e38f;
     return;
@@ -176,8 +178,8 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
-  // withdraw the estimate (bound 0) so such candidates are confirmed instead of ranked.
-  if (degenerate) { out[5] = out[6] = out[7] = 0.0f; out[9] = 3.0e38f; out[10] = -3.0e38f; }
+  // withdraw the estimate (see plane_estimate_record) so such candidates are confirmed instead of ranked.
+  if (degenerate) { out[5] = 1.0e30f; out[6] = out[7] = 0.0f; out[9] = 3.0e38f; out[10] = -3.0e38f; }
 }
 
 // sphere: the ray's line meets it iff (oc.D)^2 - |D|^2 (|oc|^2 - r^2) >= 0   (numpy/renderer.py:20-25).
