@@ -237,6 +237,51 @@ __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, cons
   resolve_lex(F, hit_any64(type, R, F.o, d, TCH), gidx, best, besti);
 }
 
+// The fp64 record of a pixel's front candidate, fetched ahead of its use (see the finish rounds): up to eight doubles
+// in registers (all of a disc, plane or sphere record; normal and plane offset of a triangle), plus the material
+// index for the fragment stage.  g < 0 (no front candidate) fetches primitive 0, and nobody looks at the result.
+template <bool TCH>
+struct FrontRecord {
+  int g, type, m;
+  const double* R;
+  double v[8];
+  __device__ __forceinline__ void fetch(const FrameDev& F, int gidx) {
+    g = gidx;
+    const int gs = max(gidx, 0);
+    const int s = segment_of(F, gs);
+    int first = F.seg[0].first;
+    const double* base = F.seg[0].rec64;
+    const int32_t* mat = F.seg[0].mat;
+    type = F.seg[0].type;
+#pragma unroll
+    for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+      if (s == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec64; mat = F.seg[i].mat; }
+    const int li = gs - first;
+    const int stride = type == SRH_PRIM_DISK ? kRec64Stride[0] : type == SRH_PRIM_PLANE ? kRec64Stride[1]
+                     : type == SRH_PRIM_SPHERE ? kRec64Stride[2] : kRec64Stride[3];
+    R = base + (size_t)li * stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = R[i];
+    if (type == SRH_PRIM_DISK || type == SRH_PRIM_TRIANGLE) {
+#pragma unroll
+      for (int i = 4; i < 8; ++i) v[i] = R[i];
+    } else {
+#pragma unroll
+      for (int i = 4; i < 8; ++i) v[i] = 0.0;
+    }
+    m = clampi(mat[li], 0, F.nmat - 1);
+  }
+  __device__ __forceinline__ double hit(const FrameDev& F, const double d[3]) const {
+    switch (type) {
+      case SRH_PRIM_DISK: return hit_disk64(v, d);
+      case SRH_PRIM_PLANE: return hit_plane64(v, d);
+      case SRH_PRIM_SPHERE: return TCH ? hit_sphere64_tch(v, d) : hit_sphere64(v, d);
+      default: return hit_triangle64(R, F.o, d);
+    }
+  }
+  __device__ __forceinline__ ShadeHint hint() const { return ShadeHint{g, m, {v[0], v[1], v[2]}}; }
+};
+
 // One reject record in registers: loaded with 16-byte accesses from a wave-uniform address, so the whole
 // record arrives through the scalar cache in one clause before any of it is used.
 template <int TYPE>
@@ -483,10 +528,10 @@ __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, ui
 // everything confirmed here (index 0x7fffffff = nothing), valid in every lane.
 template <bool PRETEST, bool TCH>
 __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane, int src, float cf, float rf,
-                                           float rlen, float bound, int g1, int g2, const double d[3],
+                                           float len, float bound, int g1, int g2, const double d[3],
                                            double& out_t, int& out_i) {
   SlowPixel P;
-  const float cs = readlane_f32(cf, src), ls = readlane_f32(rlen, src);
+  const float cs = readlane_f32(cf, src), ls = __builtin_amdgcn_rcpf(readlane_f32(len, src));
   P.cf[0] = P.cf[1] = f32x2{cs, cs};
   P.rlen[0] = P.rlen[1] = f32x2{ls, ls};
   P.rf = readlane_f32(rf, src);
@@ -616,7 +661,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       const int c = min(c0 + j, F.W - 1);
       double dtmp[3];
       Q.cf[j >> 1][j & 1] = (float)c;
-      Q.rlen[j >> 1][j & 1] = (float)(1.0 / pixel_ray(F, c, r, dtmp));
+      Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rcpf((float)pixel_ray(F, c, r, dtmp));   // 1.5 ulp: within the estimate's 2^-20
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     if (pretest) sweep_tile<true>(F, tile, Q);
@@ -690,8 +735,12 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       const int c = px0 + 4 * (src & 3) + j, r = py0 + (src >> 2);
       const Parked p = park[wave][j][src];
       const int gfront = front[wave][j][src];
+      // The front candidate's record and material index are requested before the ray is set up, so that their
+      // latency overlaps that arithmetic; nearly always this candidate is also the winner that gets shaded.
+      FrontRecord<TCH> fr;
+      fr.fetch(F, gfront);
       double d[3];
-      const float rlen = (float)(1.0 / pixel_ray(F, c, r, d));
+      const float len = (float)pixel_ray(F, c, r, d);
       double best = __builtin_inf();
       int besti = 0x7fffffff;
       float bound = __builtin_inff();
@@ -714,7 +763,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
               const int g = (q == 0) ? gfront : ordinal_to_global(F, tile, key_ordinal(key));
               if (q == 0) g1 = g;
               if (q == 1) g2 = g;
-              confirm_global<TCH>(F, g, d, best, besti);
+              if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
+              else confirm_global<TCH>(F, g, d, best, besti);
               bound = float_above(best);
             }
           }
@@ -731,8 +781,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
         todo &= todo - 1;
         double st;
         int si;
-        if (pretest) slow_pixel<true, TCH>(F, tile, lane, sl, (float)c, (float)r, rlen, bound, g1, g2, d, st, si);
-        else slow_pixel<false, TCH>(F, tile, lane, sl, (float)c, (float)r, rlen, bound, g1, g2, d, st, si);
+        if (pretest) slow_pixel<true, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        else slow_pixel<false, TCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
         if (lane == sl && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
           best = st;
           besti = si;
@@ -745,7 +795,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
 #ifdef SRH_ABL_NOSHADE
         rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __int_as_float(p.k1);
 #else
-        shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr);
+        const ShadeHint hint = fr.hint();
+        shade_pixel_t<TCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr, &hint);
 #endif
         const size_t row = (size_t)(r - F.row0);
         float* px = image + row * F.img_stride + 3 * (size_t)c;

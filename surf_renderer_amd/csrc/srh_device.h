@@ -226,9 +226,16 @@ __device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
 // the light loop and go straight to tonemap(0).
 // Arithmetic is fp64; vectors are normalised by multiplying with rsqrt_newton(|v|^2) instead of dividing
 // each component by sqrt(|v|^2) (equal to ~1e-16, immaterial after the fp32 store).
+// What a caller that already fetched the winner's record can hand to the fragment stage: valid when win == g.
+struct ShadeHint {
+  int g;              // global primitive index the hint belongs to (-1: none)
+  int m;              // its material index, clamped
+  double n[3];        // its unit normal (planar types; unused for spheres)
+};
+
 template <bool TCH>
 __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
-                                              float rgb[3], float aux[6] = nullptr) {
+                                              float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr) {
   const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
   if (aux) {
 #pragma unroll
@@ -259,12 +266,14 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     const double inv_t = (len2 + 3.0e-10 > 0.0) ? rsqrt_newton(len2 + 3.0e-10) : 1.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) n[i] = TCH ? v[i] * inv_t : (ok ? v[i] * inv : 0.0);
+  } else if (hint && hint->g == win) {
+    n[0] = hint->n[0]; n[1] = hint->n[1]; n[2] = hint->n[2];
   } else {
     // unit normal as k_prep normalised it (ops.normalize, zero vectors stay zero, numpy/ops.py:18-26)
     const double* R = S.rec64 + (size_t)li * kRec64Stride[S.type];
     n[0] = R[0]; n[1] = R[1]; n[2] = R[2];
   }
-  const int m = clampi(S.mat[li], 0, F.nmat - 1);
+  const int m = (hint && hint->g == win) ? hint->m : clampi(S.mat[li], 0, F.nmat - 1);
   const double alb[3] = {(double)F.albedo[3 * m], (double)F.albedo[3 * m + 1], (double)F.albedo[3 * m + 2]};
   if (aux) {
 #pragma unroll
