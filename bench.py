@@ -29,8 +29,12 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_F32_PEAK_TFLOPS = 157.3   # fp32 vector peak
-FLOP_PER_DISK_TEST = 17        # SURVEY.md section 8d (arithmetic only, per-primitive constants hoisted)
+# What actually bounds the render kernel is vector-instruction issue.  Its loops are VOP3-class instructions (fma,
+# med3, bfi, packed f32, fp64), which a SIMD issues at one wave-instruction per 4 cycles whatever the number of
+# waves (tools/ubench_valu.hip: 1.75-1.85 ns; only plain add/mul/logic reach 2 cycles): 1024 SIMDs x 2.4 GHz / 4.
+VALU_PEAK_GINSTR_S = 614.4
+# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_c_pmc_counters.txt)
+VALU_WAVE_INSTR_PER_LAUNCH = 55.0e6
 
 
 def parse():
@@ -45,6 +49,9 @@ def parse():
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight: each has its own stream, scratch and output buffers, so the binning "
                          "kernels of one frame overlap the render kernel of another")
+    ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
+                    help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
+                         "(default), or one gather per frame to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
     return ap.parse_args()
@@ -90,7 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from surf_renderer_amd import _lib, renderer, synthetic
-    from surf_renderer_amd.dist import gather_rows, row_slab
+    from surf_renderer_amd.dist import exchange_frames, gather_rows, row_slab
 
     W, H, M = args.width, args.height, args.prims
     scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
@@ -99,50 +106,103 @@ def main():
     r0, r1 = row_slab(H, rank, world)
     h = r1 - r0
 
-    # One (rows, 4W) fp32 slab per rank -- [W x rgb | W x depth] per row -- so a single gather moves both; rank 0
-    # renders straight into its rows of the full (H, 4W) frame.  Two frames are kept in flight: the gather of frame
-    # i (RCCL, its own stream) overlaps the render of frame i+1, and a buffer is reused only after its gather is done.
-    n_buf = max(1, args.inflight)
-    streams = [torch.cuda.Stream(device) for _ in range(n_buf)]
-    scratch = [buf.new_workspace(W, H) for _ in range(n_buf)]
-    frames, slabs, images, depths = [], [], [], []
-    for _ in range(n_buf):
-        if rank == 0:
-            frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
-            slab = frame[r0:r1]
-        else:
-            frame = None
-            slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
-        frames.append(frame)
-        slabs.append(slab)
-        images.append(slab.as_strided((h, W, 3), (4 * W, 3, 1), slab.storage_offset()))
-        depths.append(slab.as_strided((h, W), (4 * W, 1), slab.storage_offset() + 3 * W))
+    # Framebuffer layout: (rows, 4W) fp32 per slab -- [W x rgb | W x depth] per row -- so one transfer moves both.
+    # `inflight` frames are in flight on their own streams with their own scratch (binning of one frame overlaps the
+    # render of another).
+    #   1 rank    frames are rendered in place.
+    #   P ranks   frames are gathered in BATCHES of P with rotating roots: frame k of a batch is assembled on rank k
+    #             by one all-to-all (surf_renderer_amd.dist.exchange_frames) -- per frame the same bytes as a gather to
+    #             rank 0, but spread over every rank's xGMI links; two batches are buffered so the exchange of one
+    #             overlaps the rendering of the next.  (--gather root0: the plain one-gather-per-frame to rank 0.)
+    n_str = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device) for _ in range(n_str)]
+    scratch = [buf.new_workspace(W, H) for _ in range(n_str)]
+    equal_slabs = H % world == 0
+    batched = world > 1 and equal_slabs and args.gather == "alltoall"
+    main = torch.cuda.current_stream(device)
     events = [_lib.EventPair() for _ in range(args.steps)]
-    pending = [None] * n_buf
     counter = [0]
 
-    def step(ev=None):
-        b = counter[0] % n_buf
-        counter[0] += 1
-        if pending[b] is not None:
-            with torch.cuda.stream(streams[b]):
-                pending[b].wait()                  # this buffer's previous frame has left
-            pending[b] = None
-        with torch.cuda.stream(streams[b]):
-            renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(images[b], depths[b], None),
-                                    events=ev, workspace=scratch[b])
-            if world > 1:
-                pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
+    def views(slab):
+        hh = slab.shape[0]
+        return (slab.as_strided((hh, W, 3), (4 * W, 3, 1), slab.storage_offset()),
+                slab.as_strided((hh, W), (4 * W, 1), slab.storage_offset() + 3 * W))
 
-    def fence():
-        for b in range(n_buf):
-            if pending[b] is not None:
-                pending[b].wait()
+    if batched:
+        n_bat = 2
+        send = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
+        recv = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
+        pending = [None] * n_bat
+
+        def exchange(b):
+            for s_ in streams:
+                main.wait_stream(s_)               # every slab of the batch is rendered
+            pending[b] = exchange_frames(send[b], recv[b], async_op=True)
+
+        def step(ev=None):
+            i = counter[0]
+            counter[0] += 1
+            b, k = (i // world) % n_bat, i % world
+            if k == 0 and pending[b] is not None:
+                pending[b].wait()                  # main stream: this buffer's previous batch has left
                 pending[b] = None
-        torch.cuda.synchronize(device)
-        if world > 1:
+                for s_ in streams:
+                    s_.wait_stream(main)
+            image, depth = views(send[b][k])
+            with torch.cuda.stream(streams[i % n_str]):
+                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
+                                        events=ev, workspace=scratch[i % n_str])
+            if k == world - 1:
+                exchange(b)
+
+        def fence():
+            i = counter[0]
+            if i % world:                          # deliver the unfinished batch too (its empty slots travel as they are)
+                exchange((i // world) % n_bat)
+                counter[0] = (i // world + 1) * world
+            for b in range(n_bat):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+            torch.cuda.synchronize(device)
             dist.barrier()
-        torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)
+    else:
+        n_buf = n_str
+        frames, slabs = [], []
+        for _ in range(n_buf):
+            if rank == 0:
+                frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
+                slab = frame[r0:r1]
+            else:
+                frame = None
+                slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
+            frames.append(frame)
+            slabs.append(slab)
+        pending = [None] * n_buf
+
+        def step(ev=None):
+            b = counter[0] % n_buf
+            counter[0] += 1
+            with torch.cuda.stream(streams[b]):
+                if pending[b] is not None:
+                    pending[b].wait()              # this buffer's previous frame has left
+                    pending[b] = None
+                image, depth = views(slabs[b])
+                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
+                                        events=ev, workspace=scratch[b])
+                if world > 1:
+                    pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
+
+        def fence():
+            for b in range(n_buf):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         step()
@@ -168,8 +228,8 @@ def main():
         # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
         alg_bytes = M * 40.0 + h * W * (12.0 + 4.0)
         ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        rank_tests = float(M) * W * h
-        valu_tflops = rank_tests * FLOP_PER_DISK_TEST / (kernel_ms * 1e-3) / 1e12
+        default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned")
+        ginstr_s = VALU_WAVE_INSTR_PER_LAUNCH / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "gtests_per_s": fps * tests / 1e9,
@@ -181,16 +241,21 @@ def main():
             "config": {"workload": "BASELINE configs[4]: 100k synthetic disk splats, 2048x2048, forward render, "
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
-                       "frames_in_flight": n_buf,
-                       "parallelism": f"rows/{world}"},
+                       "frames_in_flight": n_str,
+                       "parallelism": f"rows/{world}",
+                       "collection": "none" if world == 1 else
+                                     (f"all-to-all per {world} frames, frame k on rank k" if batched
+                                      else "gather to rank 0 per frame")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes,
-                         "note": "the path is VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
-            "valu": {"achieved": valu_tflops, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": valu_tflops / VALU_F32_PEAK_TFLOPS,
-                     "flop_per_test": FLOP_PER_DISK_TEST, "tests_per_launch": rank_tests},
+                         "note": "the kernel is bound by vector-instruction issue, not by HBM; see valu_issue"},
+            "valu_issue": ({"achieved": ginstr_s, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
+                            "frac": ginstr_s / VALU_PEAK_GINSTR_S,
+                            "wave_instr_per_launch": VALU_WAVE_INSTR_PER_LAUNCH,
+                            "source": "SQ_INSTS_VALU (profiles/) over the live kernel time; peak = one VOP3-class "
+                                      "instruction per SIMD per 4 cycles"} if default_workload else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)

@@ -76,3 +76,37 @@ def gather_rows(slab: torch.Tensor, full: Optional[torch.Tensor], height: int, d
     if not async_op:
         handle.wait()
     return handle
+
+
+def exchange_frames(send: torch.Tensor, recv: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                    async_op: bool = False) -> GatherHandle:
+    """Gather a BATCH of P = world frames at once, frame k of the batch on rank k.
+
+    ``send`` (P, h, ...) holds this rank's row slab of P consecutive frames; on return ``recv`` (P, h, ...) holds,
+    on rank k, slab g of frame k from every rank g -- with equal slabs ``recv.view(H, ...)`` IS the assembled frame k.
+    Per frame this moves exactly what a gather to one root moves, but as one all-to-all per P frames every rank
+    receives over all of its xGMI links at once instead of rank 0 receiving everything over its own: a 2048 x 2048
+    fp32 rgb+depth frame is 67 MB, and a single root's links cap a fixed-root gather at a few thousand frames/s.
+    NCCL/RCCL: one ``all_to_all_single``; other backends (gloo in the CPU tests): one batched send/recv group."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if send.shape != recv.shape or send.shape[0] != world:
+        raise ValueError(f"send and recv must both be ({world}, h, ...), got {tuple(send.shape)} and {tuple(recv.shape)}")
+    if not (send.is_contiguous() and recv.is_contiguous()):
+        raise ValueError("send and recv must be contiguous")
+    if world == 1:
+        recv.copy_(send)
+        return GatherHandle()
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_to_all_single(recv, send, group=group, async_op=async_op)
+        return GatherHandle([work] if async_op else [])
+    recv[rank].copy_(send[rank])
+    ops = []
+    for g in range(world):
+        if g != rank:
+            ops.append(dist.P2POp(dist.isend, send[g], g, group))
+            ops.append(dist.P2POp(dist.irecv, recv[g], g, group))
+    handle = GatherHandle(dist.batch_isend_irecv(ops))
+    if not async_op:
+        handle.wait()
+    return handle

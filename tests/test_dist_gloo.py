@@ -82,3 +82,40 @@ def test_two_rank_row_slab_gather(height):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from surf_renderer_amd.dist import exchange_frames
+        h, w = 3, 5
+        # slab of rank g for frame k of the batch carries the value 100 g + k in every element
+        send = torch.stack([torch.full((h, w), 100.0 * rank + k) for k in range(world)])
+        recv = torch.full((world, h, w), -1.0)
+        exchange_frames(send, recv, async_op=(rank % 2 == 0)).wait()
+        want = torch.stack([torch.full((h, w), 100.0 * g + rank) for g in range(world)])
+        q.put((rank, bool(torch.equal(recv, want))))
+        bad = torch.zeros((world + 1, h, w))
+        try:
+            exchange_frames(bad, bad.clone())
+            q.put((rank, False))
+        except ValueError:
+            q.put((rank, True))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batched_frame_exchange_puts_frame_k_on_rank_k(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = [q.get(timeout=5) for _ in range(2 * world)]
+    assert all(ok for _, ok in got), got
