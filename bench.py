@@ -52,6 +52,12 @@ def parse():
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
                          "(default), or one gather per frame to rank 0")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay each frame's kernel sequence (memset, prep, count, scan, fill, render) as one "
+                         "hipGraph per output slot instead of six launches; auto = on, eager if capture fails")
+    ap.add_argument("--as-rank", default=None, metavar="R/P",
+                    help="single-process rehearsal: render only the row slab rank R of a P-rank job would own (no "
+                         "collection), to size the per-rank cost of the multi-GPU path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
     return ap.parse_args()
@@ -104,6 +110,9 @@ def main():
     buf = renderer.flatten_scene(scene, device)
     cam = renderer.camera_struct(scene["camera"])
     r0, r1 = row_slab(H, rank, world)
+    if args.as_rank:
+        er, ep = (int(t) for t in args.as_rank.split("/"))
+        r0, r1 = row_slab(H, er, ep)
     h = r1 - r0
 
     # Framebuffer layout: (rows, 4W) fp32 per slab -- [W x rgb | W x depth] per row -- so one transfer moves both.
@@ -120,8 +129,41 @@ def main():
     equal_slabs = H % world == 0
     batched = world > 1 and equal_slabs and args.gather == "alltoall"
     main = torch.cuda.current_stream(device)
-    events = [_lib.EventPair() for _ in range(args.steps)]
+    # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
+    # step; those steps launch eagerly, the others replay graphs
+    ev_every = 1 if args.graph == "off" else 8
+    events = [_lib.EventPair() if i % ev_every == 0 else None for i in range(args.steps)]
     counter = [0]
+
+    graphs = {}
+    graph_state = {"on": args.graph != "off", "captured": 0}
+
+    def enqueue(key, stream, image, depth, ws, ev):
+        """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,
+        eager launches the first time, when a timing event pair is to be recorded, or when graphs are off."""
+        if graph_state["on"] and ev is None:
+            g = graphs.get(key)
+            if g is None:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
+                                                workspace=ws)
+                    graphs[key] = g
+                    graph_state["captured"] += 1
+                except Exception as exc:                      # capture unsupported here: stay eager, say so
+                    if args.graph == "on":
+                        raise
+                    print(f"[bench] hipGraph capture failed ({exc!r}); eager launches", file=sys.stderr)
+                    graph_state["on"] = False
+                    g = None
+            if g is not None:
+                with torch.cuda.stream(stream):
+                    g.replay()
+                return
+        with torch.cuda.stream(stream):
+            renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
+                                    events=ev, workspace=ws)
 
     def views(slab):
         hh = slab.shape[0]
@@ -149,9 +191,7 @@ def main():
                 for s_ in streams:
                     s_.wait_stream(main)
             image, depth = views(send[b][k])
-            with torch.cuda.stream(streams[i % n_str]):
-                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
-                                        events=ev, workspace=scratch[i % n_str])
+            enqueue((b, k, i % n_str), streams[i % n_str], image, depth, scratch[i % n_str], ev)
             if k == world - 1:
                 exchange(b)
 
@@ -173,7 +213,7 @@ def main():
         for _ in range(n_buf):
             if rank == 0:
                 frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
-                slab = frame[r0:r1]
+                slab = frame[r0:r1] if not args.as_rank else torch.empty((h, 4 * W), dtype=torch.float32, device=device)
             else:
                 frame = None
                 slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
@@ -184,14 +224,14 @@ def main():
         def step(ev=None):
             b = counter[0] % n_buf
             counter[0] += 1
-            with torch.cuda.stream(streams[b]):
-                if pending[b] is not None:
+            if pending[b] is not None:
+                with torch.cuda.stream(streams[b]):
                     pending[b].wait()              # this buffer's previous frame has left
-                    pending[b] = None
-                image, depth = views(slabs[b])
-                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
-                                        events=ev, workspace=scratch[b])
-                if world > 1:
+                pending[b] = None
+            image, depth = views(slabs[b])
+            enqueue((b,), streams[b], image, depth, scratch[b], ev)
+            if world > 1:
+                with torch.cuda.stream(streams[b]):
                     pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
 
         def fence():
@@ -217,9 +257,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([e.elapsed_ms() for e in events]))
+    kernel_ms = float(np.mean([e.elapsed_ms() for e in events if e is not None]))
     for e in events:
-        e.close()
+        if e is not None:
+            e.close()
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -228,7 +269,8 @@ def main():
         # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
         alg_bytes = M * 40.0 + h * W * (12.0 + 4.0)
         ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned")
+        default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned") \
+            and not args.as_rank
         ginstr_s = VALU_WAVE_INSTR_PER_LAUNCH / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
@@ -242,7 +284,9 @@ def main():
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
                        "frames_in_flight": n_str,
-                       "parallelism": f"rows/{world}",
+                       "launch": f"hipGraph replay ({graph_state['captured']} graphs)" if graph_state["on"] and graphs
+                                 else "eager",
+                       "parallelism": f"rows/{world}" if not args.as_rank else f"rehearsal of rank {args.as_rank}",
                        "collection": "none" if world == 1 else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},
