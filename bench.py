@@ -146,7 +146,8 @@ def main():
             if g is None:
                 try:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream):
+                    # thread_local: the process group's watchdog thread may query events while we capture
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                         renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
                                                 workspace=ws)
                     graphs[key] = g
@@ -191,7 +192,7 @@ def main():
                 for s_ in streams:
                     s_.wait_stream(main)
             image, depth = views(send[b][k])
-            enqueue((b, k, i % n_str), streams[i % n_str], image, depth, scratch[i % n_str], ev)
+            enqueue((b, k), streams[k % n_str], image, depth, scratch[k % n_str], ev)
             if k == world - 1:
                 exchange(b)
 
@@ -244,6 +245,16 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(device)
 
+    # capture every output slot's graph up front, before any collective is in flight
+    if graph_state["on"]:
+        if batched:
+            for b in range(n_bat):
+                for k in range(world):
+                    enqueue((b, k), streams[k % n_str], *views(send[b][k]), scratch[k % n_str], None)
+        else:
+            for b in range(n_buf):
+                enqueue((b,), streams[b], *views(slabs[b]), scratch[b], None)
+        torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         step()
     fence()

@@ -120,7 +120,7 @@ typedef struct SrhParams {
   int32_t shading;              /* SRH_SHADING_* */
   int32_t double_sided;         /* torch shading: flip the normal towards the viewer (torch/renderer.py:107-112) */
   int32_t use_quartic;          /* torch shading: attenuation uses d^4 instead of d^2 (torch/renderer.py:92) */
-  int32_t reserved0;
+  int32_t waves_per_tile;       /* binned mode: 0 = choose by tile count, 1 or 4 = force (tuning / tests; same result) */
   float* normal_out;            /* optional (rows,W,3) dense: unit normal of the hit, 0 where nothing is hit */
   float* pos_out;               /* optional (rows,W,3) dense: hit point, 0 where nothing is hit */
   int64_t image_row_stride;     /* elements between consecutive output rows; 0 = dense (3*W, W, W). */

@@ -50,7 +50,7 @@ class SrhMaterials(C.Structure):
 class SrhParams(C.Structure):
     _fields_ = [("row0", C.c_int32), ("row1", C.c_int32), ("mode", C.c_int32),
                 ("tonemap_gamma", C.c_int32), ("gamma", C.c_double),
-                ("shading", C.c_int32), ("double_sided", C.c_int32), ("use_quartic", C.c_int32), ("reserved0", C.c_int32),
+                ("shading", C.c_int32), ("double_sided", C.c_int32), ("use_quartic", C.c_int32), ("waves_per_tile", C.c_int32),
                 ("normal_out", C.c_void_p), ("pos_out", C.c_void_p),
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),

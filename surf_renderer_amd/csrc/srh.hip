@@ -46,10 +46,52 @@ size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 // ------------------------------------------------------------------------------------------------
 __device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R);
 
+// Can no pixel of rows [row0, row1) see anything of the ball (centre x relative to the eye, radius rho)?  The ball's
+// points have a in a0 +- rho |m_a| and g in g0 +- rho |m_g| (Cauchy-Schwarz) and lie on image row g / a; rays exist
+// only through integer rows, hence the half-row slack.  A ball that reaches the eye plane (a <= 0) is kept.
+__device__ inline bool ball_misses_slab(const FrameDev& F, const double x[3], double rho) {
+  const double a0 = dot3(F.slab_ma, x), g0 = dot3(F.slab_mg, x);
+  const double a_lo = a0 - rho * F.slab_na, a_hi = a0 + rho * F.slab_na;
+  const double g_lo = g0 - rho * F.slab_ng, g_hi = g0 + rho * F.slab_ng;
+  if (!(a_lo > 0.0) || !isfinite(a_hi + g_lo + g_hi)) return false;
+  const double r_lo = g_lo / (g_lo >= 0.0 ? a_hi : a_lo), r_hi = g_hi / (g_hi >= 0.0 ? a_lo : a_hi);
+  return r_hi < (double)F.row0 - 0.5 || r_lo > (double)F.row1 - 0.5;
+}
+
+// multi-GPU row slabs: most primitives project outside a rank's rows; they are recognised from their bounding ball
+// before any of the per-frame records is computed, and are simply not binned (no list refers to their records)
+__device__ inline bool primitive_misses_slab(const FrameDev& F, const SegDev& S, int i) {
+  double x[3], rho;
+  if (S.type == SRH_PRIM_DISK || S.type == SRH_PRIM_SPHERE) {
+    const float* c = S.pos + 4 * (size_t)i;
+    for (int k = 0; k < 3; ++k) x[k] = (double)c[k] - F.o[k];
+    rho = fabs((double)S.radius[i]);
+  } else if (S.type == SRH_PRIM_TRIANGLE) {
+    const float* f = S.face + 12 * (size_t)i;
+    double cen[3];
+    for (int k = 0; k < 3; ++k) cen[k] = ((double)f[k] + (double)f[4 + k] + (double)f[8 + k]) / 3.0;
+    rho = 0.0;
+    for (int v = 0; v < 3; ++v) {
+      const double w[3] = {(double)f[4 * v] - cen[0], (double)f[4 * v + 1] - cen[1], (double)f[4 * v + 2] - cen[2]};
+      rho = fmax(rho, sqrt(dot3(w, w)));
+    }
+    rho *= 1.0000001;
+    for (int k = 0; k < 3; ++k) x[k] = cen[k] - F.o[k];
+  } else {
+    return false;
+  }
+  return ball_misses_slab(F, x, rho);
+}
+
 __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
+  if (F.tilerange && F.slab_cull && primitive_misses_slab(F, S, i)) {
+    uint16_t* tr = F.tilerange + 4 * (size_t)(S.first + i);
+    tr[0] = 1; tr[1] = 0; tr[2] = 0; tr[3] = 0;                   // not binned
+    return;
+  }
   double* R = rec64 + (size_t)i * kRec64Stride[S.type];
   prep_record64(S, i, F.o, F.shading != 0, R);
   // screen-space reject record of the FAST / binned modes, from the fp64 record just written
@@ -527,6 +569,21 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     F.tile_off = (uint32_t*)(ws + L.tile_off);
     F.large = (uint32_t*)(ws + L.large);
     F.entries = (uint32_t*)(ws + L.entries);
+    F.slab_cull = 0;
+    if (F.row0 > 0 || F.row1 < F.H) {
+      // rows of [D0 Dc Dr]^-1 via the adjugate (cross products)
+      const PixelBasis B = pixel_basis(F);
+      const double* p0 = B.D0; const double* pc = B.Dc; const double* pr = B.Dr;
+      const double cx[3] = {pc[1] * pr[2] - pc[2] * pr[1], pc[2] * pr[0] - pc[0] * pr[2], pc[0] * pr[1] - pc[1] * pr[0]};
+      const double cg[3] = {p0[1] * pc[2] - p0[2] * pc[1], p0[2] * pc[0] - p0[0] * pc[2], p0[0] * pc[1] - p0[1] * pc[0]};
+      const double det = p0[0] * cx[0] + p0[1] * cx[1] + p0[2] * cx[2];
+      if (std::isfinite(det) && std::fabs(det) > 0.0) {
+        for (int k = 0; k < 3; ++k) { F.slab_ma[k] = cx[k] / det; F.slab_mg[k] = cg[k] / det; }
+        F.slab_na = std::sqrt(F.slab_ma[0] * F.slab_ma[0] + F.slab_ma[1] * F.slab_ma[1] + F.slab_ma[2] * F.slab_ma[2]) * 1.000001;
+        F.slab_ng = std::sqrt(F.slab_mg[0] * F.slab_mg[0] + F.slab_mg[1] * F.slab_mg[1] + F.slab_mg[2] * F.slab_mg[2]) * 1.000001;
+        F.slab_cull = std::isfinite(F.slab_na) && std::isfinite(F.slab_ng) ? 1 : 0;
+      }
+    }
     hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);
     if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
   }
@@ -544,8 +601,16 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {
     const unsigned groups = binned_grid(F);   // whole regions of tiles, a multiple of 8 of them (see k_render_binned)
-    if (F.shading) hipLaunchKernelGGL(k_render_binned<true>, dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
-    else hipLaunchKernelGGL(k_render_binned<false>, dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+    // one wave per tile while that still gives every SIMD several waves; four waves per tile for small frames / slabs
+    const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4) ? params->waves_per_tile == 4
+                                                                                   : binned_waves_per_tile(F) == 4;
+    if (F.shading) {
+      if (split) hipLaunchKernelGGL((k_render_binned<true, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
+      else hipLaunchKernelGGL((k_render_binned<true, 1>), dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+    } else {
+      if (split) hipLaunchKernelGGL((k_render_binned<false, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
+      else hipLaunchKernelGGL((k_render_binned<false, 1>), dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+    }
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);

@@ -391,22 +391,22 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 // Scalar loads complete out of order, so the only wait is "all of them": the loop is unrolled by two over two
 // record buffers A and B -- while A is evaluated, B's record (and the list word after it) is in flight, and the
 // wait for B comes only after A's ~100 vector instructions.  No register copies between the buffers.
-template <int TYPE, bool PRETEST>
-__device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n,
-                                           uint32_t ord0, QuadState& Q) {
-  if (n == 0) return;
+template <int TYPE, bool PRETEST, int WPT>
+__device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
+                                           uint32_t ord0, QuadState& Q, uint32_t part) {
+  // with WPT waves per tile this wave takes entries part, part + WPT, ...
+  if (n_all <= part) return;
+  const uint32_t n = (n_all - part + WPT - 1) / WPT;
   RejectRecord<TYPE> A, B;
   const float* base = S.rec32;
   const int first = S.first;
 #if defined(SRH_ABL_SEQREC)     // timing experiment (wrong results): records read sequentially, no list indirection
   const uint32_t seq0 = (uint32_t)(((size_t)list >> 2) % (size_t)max(S.count - (int)n, 1));
   auto entry = [&](uint32_t k) { return first + (int)(seq0 + min(k, n - 1)); };
-#elif defined(SRH_ABL_SAMEREC)  // timing experiment (wrong results): every entry reads the list's first record
-  const int g0 = (int)list[0];
-  auto entry = [&](uint32_t k) { return g0 + 0 * (int)list[min(k, n - 1)]; };
 #else
-  auto entry = [&](uint32_t k) { return (int)list[min(k, n - 1)]; };
+  auto entry = [&](uint32_t k) { return (int)list[min(k, n - 1) * WPT + part]; };
 #endif
+  auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, kOrdMask); };
   int gA = entry(0);
   int gB = entry(1);
   A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
@@ -415,13 +415,13 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
     B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
     gA = entry(i + 2);
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
-    sweep_entry<TYPE, PRETEST>(A, min(ord0 + i + 1, kOrdMask), Q);
+    sweep_entry<TYPE, PRETEST>(A, field(i), Q);
     if (i + 1 >= n) break;
     __builtin_amdgcn_sched_barrier(0);
     A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
     gB = entry(i + 3);
     __builtin_amdgcn_sched_barrier(0);
-    sweep_entry<TYPE, PRETEST>(B, min(ord0 + i + 2, kOrdMask), Q);
+    sweep_entry<TYPE, PRETEST>(B, field(i + 1), Q);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -487,8 +487,8 @@ struct TileLists {
   }
 };
 
-template <bool PRETEST>
-__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q) {
+template <bool PRETEST, int WPT>
+__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part) {
   const TileLists L{F, tile};
   uint32_t ord0 = 0;
   for (int s = 0; s < F.nseg; ++s) {
@@ -498,10 +498,10 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
       switch (S.type) {
-        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST>(S, list, n, ord0, Q); break;
-        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST>(S, list, n, ord0, Q); break;
-        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST>(S, list, n, ord0, Q); break;
-        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST>(S, list, n, ord0, Q); break;
+        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
+        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
+        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
+        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
       }
       ord0 += n;
     }
@@ -590,12 +590,18 @@ __host__ __device__ inline unsigned binned_regions_x(const FrameDev& F) {
   return (((unsigned)F.tiles_x + 3u) / 4u + kRegionW - 1u) / kRegionW;
 }
 
-// grid size: whole regions, rounded up to a multiple of 8 regions
+// number of 4-tile groups launched: whole regions, rounded up to a multiple of 8 regions
 __host__ inline unsigned binned_grid(const FrameDev& F) {
   const unsigned tiles_y = (unsigned)F.tiles_y;
   const unsigned regions = binned_regions_x(F) * ((tiles_y + kRegionH - 1u) / kRegionH);
   return ((regions + 7u) & ~7u) * (kRegionW * kRegionH);
 }
+
+#ifndef SRH_SPLIT_TILES
+#define SRH_SPLIT_TILES 3072
+#endif
+// waves per tile of the render kernel (see k_render_binned): 4 below SRH_SPLIT_TILES tiles, else 1
+__host__ inline int binned_waves_per_tile(const FrameDev& F) { return F.ntiles < SRH_SPLIT_TILES ? 4 : 1; }
 
 // inclusive prefix sum of one int per lane across the wave
 __device__ __forceinline__ int wave_prefix_incl(int v, int lane) {
@@ -621,7 +627,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // The finish phase is COMPACTED: after the sweep the tile's pixels that have at least one candidate are queued
 // (row-major) in LDS and handed out 64 at a time, so a tile that is 40 % covered costs two fp64 rounds instead
 // of four; pixels without a candidate are background and stored straight away.
-template <bool TCH>
+// WPT = waves per tile.  1: a workgroup renders four tiles, one per wave (most work per launched wave).  4: a
+// workgroup renders ONE tile -- each wave sweeps a quarter of the tile's entries for all 256 pixels, the per-pixel
+// keys are merged through LDS, and each wave finishes a quarter of the pixels.  Same arithmetic, a quarter of the
+// latency per tile and four times the waves: for frames (or row slabs of a multi-GPU job) with too few tiles to
+// fill 1024 SIMDs several times over.
+template <bool TCH, int WPT>
 __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
@@ -631,15 +642,19 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
   const int lane = threadIdx.x & 63;
   int tx, ty;
   {
-    const unsigned idx = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    // `group` = four tiles that are neighbours in x: one workgroup (WPT 1) or four consecutive ones on the same XCD
+    const unsigned seq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const unsigned idx = WPT == 1 ? seq : seq >> 2;
+    const unsigned sub = WPT == 1 ? (unsigned)wave : (seq & 3u);
     const unsigned q = idx / (kRegionW * kRegionH), within = idx % (kRegionW * kRegionH);
     const unsigned nrx = binned_regions_x(F);
     const unsigned region = q * 8u + ((xcd + 3u * ((q * 8u) / nrx)) & 7u);   // rotate the deal from one region row to the next
     const unsigned rx = region % nrx, ry = region / nrx;
-    tx = (int)((rx * kRegionW + within % kRegionW) * 4u) + wave;
+    tx = (int)((rx * kRegionW + within % kRegionW) * 4u + sub);
     ty = (int)(ry * kRegionH + within / kRegionW);
   }
-  if (tx >= F.tiles_x || ty >= F.tiles_y) return;              // waves are independent: no block barrier below
+  // WPT 1: waves are independent, no block barrier below.  WPT 4: the whole workgroup shares the tile and leaves together.
+  if (tx >= F.tiles_x || ty >= F.tiles_y) return;
   const int tile = ty * F.tiles_x + tx;
   const int px0 = tx * kTile, py0 = F.row0 + ty * kTile;
   const int c0 = px0 + 4 * (lane & 3);
@@ -651,7 +666,8 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
   const bool pretest = F.near_clip > 0.0;     // with near <= 0 a negative t can be valid: confirm every candidate
 #endif
   const bool want_aux = F.normal_out || F.pos_out;
-  uint32_t has = 0;                           // bit j: pixel j of the quad exists and has a candidate
+  const uint32_t mine = WPT == 1 ? 0xFu : (1u << wave);   // pixels of the quad this wave finishes
+  uint32_t has = 0;                           // bit j: pixel j of the quad exists, is mine and has a candidate
   {
     const int r = min(r_raw, F.row1 - 1);
     QuadState Q;
@@ -664,15 +680,42 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rcpf((float)pixel_ray(F, c, r, dtmp));   // 1.5 ulp: within the estimate's 2^-20
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
-    if (pretest) sweep_tile<true>(F, tile, Q);
-    else sweep_tile<false>(F, tile, Q);
+    const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps
+    if (pretest) sweep_tile<true, WPT>(F, tile, Q, part);
+    else sweep_tile<false, WPT>(F, tile, Q, part);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Parked p;
       p.k1 = Q.k1[j]; p.k2 = Q.k2[j]; p.k3 = Q.k3[j]; p.k4 = Q.k4[j];
       park[wave][j][lane] = p;
-      if (p.k1 != kNoKey && row_live && c0 + j < F.W) has |= 1u << j;
     }
+    if (WPT > 1) {
+      // merge: pixel j = wave of every lane collects the keys the four waves found for it
+      __syncthreads();
+      const int j = wave;
+      int32_t m1 = kNoKey, m2 = kNoKey, m3 = kNoKey, m4 = kNoKey;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const Parked o = park[v][j][lane];
+        const int32_t keys[4] = {o.k1, o.k2, o.k3, o.k4};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          m4 = imed3(m3, keys[t], m4);
+          m3 = imed3(m2, keys[t], m3);
+          m2 = imed3(m1, keys[t], m2);
+          m1 = max(m1, keys[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t == j) { Q.k1[t] = m1; Q.k2[t] = m2; Q.k3[t] = m3; Q.k4[t] = m4; }
+      Parked p;
+      p.k1 = m1; p.k2 = m2; p.k3 = m3; p.k4 = m4;
+      park[wave][j][lane] = p;                  // only this wave reads or writes column j = wave from here on
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (((mine >> j) & 1u) && Q.k1[j] != kNoKey && row_live && c0 + j < F.W) has |= 1u << j;
     // the front keys' list entries, looked up here so that the four loads are in flight together and the finish
     // rounds start from a global index instead of a dependent list read
 #pragma unroll
@@ -695,7 +738,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
   }
 
   // background: what the fragment stage gives an all-miss pixel (tonemap(0), +inf or far + 1, index 0)
-  if (row_live && has != 0xFu) {
+  if (row_live && has != mine) {
     const size_t row = (size_t)(r_raw - F.row0);
     const float bg = tonemap_f32(F, 0.0);
     const float bgz = background_depth(F, __builtin_inf());
@@ -703,7 +746,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
     float* dz = depth + row * F.depth_stride + c0;
     int32_t* nr = nearest ? nearest + row * F.near_stride + c0 : nullptr;
     const bool aligned = (((uintptr_t)px | (uintptr_t)dz | (uintptr_t)nr) & 15u) == 0;
-    if (has == 0 && c0 + 3 < F.W && aligned) {
+    if (WPT == 1 && has == 0 && c0 + 3 < F.W && aligned) {
       const float4 v = make_float4(bg, bg, bg, bg);
       reinterpret_cast<float4*>(px)[0] = v; reinterpret_cast<float4*>(px)[1] = v; reinterpret_cast<float4*>(px)[2] = v;
       *reinterpret_cast<float4*>(dz) = make_float4(bgz, bgz, bgz, bgz);
@@ -711,7 +754,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (!((has >> j) & 1u) && c0 + j < F.W) {
+        if ((((mine & ~has) >> j) & 1u) && c0 + j < F.W) {
           px[3 * j] = bg; px[3 * j + 1] = bg; px[3 * j + 2] = bg;
           dz[j] = bgz;
           if (nr) nr[j] = 0;
@@ -721,7 +764,7 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
       const float zero[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (!((has >> j) & 1u) && c0 + j < F.W) store_aux(F, row, c0 + j, zero);
+        if ((((mine & ~has) >> j) & 1u) && c0 + j < F.W) store_aux(F, row, c0 + j, zero);
     }
   }
 

@@ -52,6 +52,11 @@ struct FrameDev {
   // tile binning (BINNED mode): 16x16-pixel tiles over the rendered row slab
   int32_t tiles_x, tiles_y, ntiles, ntiles_pad;   // ntiles_pad = ntiles rounded up to a multiple of 4
   int32_t nbins, pad1;                            // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile
+  // Row pre-cull of a slab render (binned mode, row0 > 0 or row1 < H): x - eye = a D0 + b Dc + g Dr puts a point on
+  // image row g / a; slab_ma / slab_mg are the rows of [D0 Dc Dr]^-1 that give a and g, slab_na / slab_ng their
+  // lengths.  slab_cull = 0 switches the test off (full frame, or a singular basis).
+  double slab_ma[3], slab_mg[3], slab_na, slab_ng;
+  int32_t slab_cull, pad3;
   uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
   uint64_t* tilemask;                // (total) bit k = tile k of the range (row-major) really overlaps the shape
   uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts | [64+nbins, 64+2 nbins) fill cursors

@@ -264,7 +264,8 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                    mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
                    want_nearest: bool = True, events: Optional[_lib.EventPair] = None,
                    workspace: Optional[torch.Tensor] = None, shading: str = "numpy", double_sided: bool = False,
-                   use_quartic: bool = False, aux: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None):
+                   use_quartic: bool = False, aux: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None,
+                   waves_per_tile: int = 0):
     """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
     enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
     preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None).  ``workspace`` overrides the
@@ -294,7 +295,7 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                             tonemap_gamma=0 if buf.gamma is None else 1,
                             gamma=1.0 if buf.gamma is None else buf.gamma,
                             shading=_lib.SHADING[shading], double_sided=int(bool(double_sided)),
-                            use_quartic=int(bool(use_quartic)),
+                            use_quartic=int(bool(use_quartic)), waves_per_tile=int(waves_per_tile),
                             normal_out=aux[0].data_ptr() if aux and aux[0] is not None else None,
                             pos_out=aux[1].data_ptr() if aux and aux[1] is not None else None,
                             image_row_stride=image.stride(0) if h > 1 else 0,
@@ -459,6 +460,7 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     ``diffrend.numpy.renderer.render`` within fp32 rounding of the stored outputs.
 
     Keyword arguments: ``device`` ('cuda'), ``mode`` ('auto' | 'exact' | 'fast' | 'binned'), ``rows`` ((r0, r1) slab),
+    ``waves_per_tile`` (0 | 1 | 4: launch shape of the binned kernel, a tuning knob with identical results),
     ``validate`` (host-side index / w checks), ``shading`` ('numpy' | 'torch').  With ``shading='torch'`` the call
     follows ``diffrend.torch.renderer.render`` instead (Phong shading with lights.attenuation / lights.ambient /
     materials.coeffs, ``double_sided``, ``use_quartic``, orthonormal camera basis, far+1 background, extra outputs
@@ -466,7 +468,7 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     and ignored.
     """
     unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate", "shading", "double_sided",
-                                                  "use_quartic"}
+                                                  "use_quartic", "waves_per_tile"}
     if unknown:
         raise TypeError(f"render() got unexpected keyword arguments {sorted(unknown)}")
     device = torch.device(params.get("device", "cuda"))
@@ -489,12 +491,14 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
         pos = torch.empty((r1 - r0, width, 3), dtype=torch.float32, device=device)
         image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode, shading="torch",
                                                double_sided=params.get("double_sided", False),
-                                               use_quartic=params.get("use_quartic", False), aux=(normal, pos))
+                                               use_quartic=params.get("use_quartic", False), aux=(normal, pos),
+                                               waves_per_tile=params.get("waves_per_tile", 0))
         return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64),
                             normal=normal, pos=pos)
     if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
         # differentiable call: image and depth carry a grad_fn backed by the analytic HIP backward
         image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, *inputs)
     else:
-        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode)
+        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode,
+                                               waves_per_tile=params.get("waves_per_tile", 0))
     return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64))

@@ -78,9 +78,11 @@ def test_caller_scene_not_modified():
 def _modes_identical(scene, modes=("exact", "fast", "binned")):
     ref = _render(scene, mode=modes[0])
     for mode in modes[1:]:
-        got = _render(scene, mode=mode)
-        for k in ("nearest", "depth", "image"):
-            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{mode} vs {modes[0]}: {k}")
+        # the binned kernel has two launch shapes (one or four waves per tile); the default picks by tile count
+        for wpt in ((0, 1, 4) if mode == "binned" else (0,)):
+            got = _render(scene, mode=mode, waves_per_tile=wpt)
+            for k in ("nearest", "depth", "image"):
+                np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{mode} (waves_per_tile {wpt}) vs {modes[0]}: {k}")
     return ref
 
 
