@@ -400,12 +400,7 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
   RejectRecord<TYPE> A, B;
   const float* base = S.rec32;
   const int first = S.first;
-#if defined(SRH_ABL_SEQREC)     // timing experiment (wrong results): records read sequentially, no list indirection
-  const uint32_t seq0 = (uint32_t)(((size_t)list >> 2) % (size_t)max(S.count - (int)n, 1));
-  auto entry = [&](uint32_t k) { return first + (int)(seq0 + min(k, n - 1)); };
-#else
   auto entry = [&](uint32_t k) { return (int)list[min(k, n - 1) * WPT + part]; };
-#endif
   auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, kOrdMask); };
   int gA = entry(0);
   int gB = entry(1);
