@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, 
   const bool near_pos = F.near_clip > 0.0;
   switch (S.type) {
     case SRH_PRIM_DISK: disk_reject_record(R, B, F.W, F.H, Q); break;
-    case SRH_PRIM_SPHERE: sphere_reject_record(R, B, F.W, F.H, near_pos, Q); break;
+    case SRH_PRIM_SPHERE: sphere_reject_record(R, B, F.W, F.H, near_pos, F.shading != 0, Q); break;
     case SRH_PRIM_TRIANGLE: triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q); break;
     default: plane_reject_record(R, B, F.W, F.H, Q); break;
   }

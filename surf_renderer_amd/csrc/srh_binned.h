@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
 constexpr uint32_t kOrdMask = 0xFFFu;
 constexpr int32_t kNoKey = 0;
 constexpr float kNoEstimate = 1.0e30f;
+constexpr int kSerialSlowMax = 2;           // more undecided pixels than this in a round: lane-parallel re-sweep
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -365,7 +366,8 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    if (!PRETEST || TYPE == SRH_PRIM_SPHERE) inv[p] = splat2(kNoEstimate);
+    if (!PRETEST) inv[p] = splat2(kNoEstimate);
+    else if (TYPE == SRH_PRIM_SPHERE) inv[p] = splat2(R[5]);    // per-sphere constant (sphere_reject_record)
     else inv[p] = den[p] * rlen[p];
   }
 }
@@ -379,7 +381,9 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
+#ifndef SRH_KEYS3
     Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
+#endif
     Q.k3[j] = imed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = imed3(Q.k1[j], key, Q.k2[j]);
     Q.k1[j] = max(Q.k1[j], key);
@@ -391,10 +395,10 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 // Scalar loads complete out of order, so the only wait is "all of them": the loop is unrolled by two over two
 // record buffers A and B -- while A is evaluated, B's record (and the list word after it) is in flight, and the
 // wait for B comes only after A's ~100 vector instructions.  No register copies between the buffers.
-template <int TYPE, bool PRETEST, int WPT>
-__device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
-                                           uint32_t ord0, QuadState& Q, uint32_t part) {
-  // with WPT waves per tile this wave takes entries part, part + WPT, ...
+template <int TYPE, int WPT, class Op>
+__device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
+                                            uint32_t ord0, uint32_t part, Op&& op) {
+  // with WPT waves per tile this wave takes entries part, part + WPT, ...;  op(record, global index, key field)
   if (n_all <= part) return;
   const uint32_t n = (n_all - part + WPT - 1) / WPT;
   RejectRecord<TYPE> A, B;
@@ -408,17 +412,53 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
   for (uint32_t i = 0; i < n; i += 2) {
     // B <- entry i+1 (clamped: reloading a valid record is harmless), then the list word of entry i+2
     B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
+    const int gNow = gA;
     gA = entry(i + 2);
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
-    sweep_entry<TYPE, PRETEST>(A, field(i), Q);
+    op(A, gNow, field(i));
     if (i + 1 >= n) break;
     __builtin_amdgcn_sched_barrier(0);
     A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
+    const int gNext = gB;
     gB = entry(i + 3);
     __builtin_amdgcn_sched_barrier(0);
-    sweep_entry<TYPE, PRETEST>(B, field(i + 1), Q);
+    op(B, gNext, field(i + 1));
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <int TYPE, bool PRETEST, int WPT>
+__device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
+                                           uint32_t ord0, QuadState& Q, uint32_t part) {
+  stream_list<TYPE, WPT>(S, list, n_all, ord0, part, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
+    sweep_entry<TYPE, PRETEST>(R, field, Q);
+  });
+}
+
+// Re-sweep, lane-parallel: every lane whose pixel is still undecided (`open`) walks the tile's list again with the
+// wave, and confirms in fp64 each candidate whose bound reaches the depth confirmed so far for ITS pixel.  The
+// entry is wave-uniform, so the records arrive by scalar loads and the fp64 confirmation runs for all lanes that
+// need it at once.  Used when several pixels of a round are undecided (overlapping coplanar splats, clouds of
+// primitives without a usable depth estimate); a lone undecided pixel is cheaper on the wave-serial walk below.
+template <int TYPE, bool PRETEST, bool TCH>
+__device__ __forceinline__ void resweep_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
+                                             uint32_t n, bool open, const f32x2 (&cf)[2], float rf,
+                                             const f32x2 (&rlen)[2], const double d[3], float& bound, double& best,
+                                             int& besti) {
+  stream_list<TYPE, 1>(S, list, n, 0u, 0u, [&](const RejectRecord<TYPE>& R, int g, uint32_t) {
+    int32_t sel[4];
+    f32x2 inv[2];
+    pair_bounds<TYPE, PRETEST>(R, cf, rf, rlen, sel, inv);
+    const float iv = inv[0][0];
+    const bool need = open && sel[0] && iv > 0.0f && inv_to_bound(iv * 1.0000005f) <= bound;
+    if (__builtin_amdgcn_ballot_w64(need)) {
+      if (need) {
+        const double* R64 = S.rec64 + (size_t)(g - S.first) * kRec64Stride[TYPE];
+        resolve_lex(F, hit_any64(TYPE, R64, F.o, d, TCH), g, best, besti);
+        bound = float_above(best);
+      }
+    }
+  });
 }
 
 // Slow path, one pixel at a time, the whole wave helping: the pixel's state is broadcast, lane l examines list
@@ -561,6 +601,29 @@ __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane
   out_i = besti;
 }
 
+template <bool PRETEST, bool TCH>
+__device__ __forceinline__ void resweep_tile(const FrameDev& F, int tile, bool open, float cf, float rf, float len,
+                                             const double d[3], float& bound, double& best, int& besti) {
+  const f32x2 cfq[2] = {f32x2{cf, cf}, f32x2{cf, cf}};
+  const float rl = __builtin_amdgcn_rcpf(len);
+  const f32x2 rlq[2] = {f32x2{rl, rl}, f32x2{rl, rl}};
+  const TileLists L{F, tile};
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t* list = L.list(s, pass);
+      const uint32_t n = L.count(s, pass);
+      switch (S.type) {
+        case SRH_PRIM_DISK: resweep_list<SRH_PRIM_DISK, PRETEST, TCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        case SRH_PRIM_PLANE: resweep_list<SRH_PRIM_PLANE, PRETEST, TCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        case SRH_PRIM_SPHERE: resweep_list<SRH_PRIM_SPHERE, PRETEST, TCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        default: resweep_list<SRH_PRIM_TRIANGLE, PRETEST, TCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+      }
+    }
+  }
+}
+
 // per-pixel result of the sweep, parked in LDS between the sweep and the finish phase
 struct alignas(16) Parked {
   int32_t k1, k2, k3, k4;
@@ -628,7 +691,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // latency per tile and four times the waves: for frames (or row slabs of a multi-GPU job) with too few tiles to
 // fill 1024 SIMDs several times over.
 template <bool TCH, int WPT>
-__global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __restrict__ image,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(FrameDev F, float* __restrict__ image,
                                                         float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
   __shared__ int32_t front[4][4][64];         // global index of each pixel's front candidate (-1: none / saturated)
@@ -792,7 +855,11 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
         const int32_t keys[3] = {p.k1, p.k2, p.k3};
         bool saturated = false;
 #pragma unroll
+#ifdef SRH_KEYS3
+        for (int q = 0; q < 2; ++q) {
+#else
         for (int q = 0; q < 3; ++q) {
+#endif
           const int32_t key = keys[q];
           if (key != kNoKey && !saturated && key_bound(key) <= bound) {
             if (key_saturated(key)) {
@@ -808,12 +875,22 @@ __global__ __launch_bounds__(256) void k_render_binned(FrameDev F, float* __rest
           }
         }
         // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
+#ifdef SRH_KEYS3
+        slow = saturated || (p.k3 != kNoKey && key_bound(p.k3) <= bound);
+#else
         slow = saturated || (p.k4 != kNoKey && key_bound(p.k4) <= bound);
+#endif
         if (slow) { g1 = g2 = -1; }           // the slow path re-confirms; cheaper than excluding three indices
       }
 #endif
 #ifndef SRH_ABL_NORESWEEP
       unsigned long long todo = __builtin_amdgcn_ballot_w64(slow);
+      if (__popcll(todo) > kSerialSlowMax) {      // several undecided pixels: all of them at once, lane-parallel
+        if (slow) { best = __builtin_inf(); besti = 0x7fffffff; bound = __builtin_inff(); }   // confirm everything that passes
+        if (pretest) resweep_tile<true, TCH>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
+        else resweep_tile<false, TCH>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
+        todo = 0;
+      }
       while (todo) {                          // wave-uniform loop over the lanes whose pixel needs the slow path
         const int sl = __builtin_ctzll(todo);
         todo &= todo - 1;

@@ -19,7 +19,7 @@
 //                  elongated ellipses use [2] ex [3] ey [4] iu [11] iv > 0: candidate iff
 //                  (u*iu)^2 + (v*iv)^2 - 1 <= 0,  u = ex*dc + ey*dr, v = ex*dr - ey*dc
 //                  [5..7] u0 u1 u2 [9] lo_u [10] hi_u : depth estimate, see plane_estimate_record
-//   sphere (12)    [0..4] as the disc, rest unused
+//   sphere (12)    [0..4] as the disc; [5] upper bound of 1 / t for the whole sphere (1e30: none)
 //   triangle (16)  {a_i, b_i, g_i} at [4i..4i+2], i < 3: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
 //                  [3] u0 [7] u1 [11] u2 [13] lo_u [14] hi_u
 //   plane (8)      [0..2] u0 u1 u2 [4] lo_u [5] hi_u; candidate iff den > hi_u
@@ -152,6 +152,15 @@ __device__ inline double conic_record(double T00, double T01, double T02, double
   return smax * sqrt(thr);
 }
 
+// Upper bound of 1 / t for every hit inside the ball of radius r around the point at eye-relative position -oc:
+// t >= |oc| - r (the ball's nearest point).  1e30 ("no estimate") when the eye is inside or on the ball.
+__device__ inline float ball_inverse_depth_bound(const double oc[3], double r) {
+  const double tmin = sqrt(dot3(oc, oc)) - r;
+  if (!(tmin > 0.0) || !isfinite(tmin)) return 1.0e30f;
+  const double inv = (1.0 + 9.5367431640625e-7) / tmin;
+  return (inv < 1.0e30) ? (float)inv * 1.0000002f : 1.0e30f;
+}
+
 // disc: | oc (n.D) + k D |^2 <= r^2 (n.D)^2   (numpy/renderer.py:69,85-88 with t = k / (n.D))
 __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, int W, int H, float* out) {
   const double* n = R;
@@ -178,15 +187,28 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
-  // withdraw the estimate (see plane_estimate_record) so such candidates are confirmed instead of ranked.
-  if (degenerate) { out[5] = 1.0e30f; out[6] = out[7] = 0.0f; out[9] = 3.0e38f; out[10] = -3.0e38f; }
+  // replace it by the bounding ball's (every hit lies in the ball, so t >= |oc| - r).  The kernel multiplies den by
+  // 1 / |D|, so the constant is scaled by the largest |D| of the image (|D| is convex: a corner) -- a little weak, valid.
+  if (degenerate) {
+    double dmax = 0.0;
+    for (int i = 0; i < 4; ++i) {
+      const double c = (i & 1) ? (double)(W - 1) : 0.0, rr = (i & 2) ? (double)(H - 1) : 0.0;
+      const double D[3] = {B.D0[0] + c * B.Dc[0] + rr * B.Dr[0], B.D0[1] + c * B.Dc[1] + rr * B.Dr[1],
+                           B.D0[2] + c * B.Dc[2] + rr * B.Dr[2]};
+      dmax = fmax(dmax, sqrt(dot3(D, D)));
+    }
+    const double u = (double)ball_inverse_depth_bound(oc, sqrt(r2)) * dmax * 1.000001;
+    out[5] = (u < 1.0e30 && isfinite(u)) ? (float)u * 1.0000002f : 1.0e30f;
+    out[6] = out[7] = 0.0f; out[9] = 3.0e38f; out[10] = -3.0e38f;
+  }
 }
 
 // sphere: the ray's line meets it iff (oc.D)^2 - |D|^2 (|oc|^2 - r^2) >= 0   (numpy/renderer.py:20-25).
 // With near <= 0 a missed line yields the valid t = 0 (Q2), so nothing may be rejected.
 __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B, int W, int H, bool near_positive,
-                                            float* out) {
+                                            bool tch, float* out) {
   rec_zero(out, 12);
+  out[5] = 1.0e30f;
   if (!near_positive) return;
   const double* oc = R;
   const double cq = R[3];
@@ -195,6 +217,23 @@ __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B
   for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
   auto T = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
   conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
+  // Depth bound.  Eye outside the sphere (cq > 0): both roots have the sign of (pos - eye).D = -oc.D.  Positive roots
+  // give t = t1 >= |oc| - r.  Negative roots are a miss under the torch semantics, but the numpy backend's sentinel
+  // turns them into t = 1.0 (Q2) -- so there the bound holds only if -oc.D > 0 on the whole image (affine: its
+  // minimum is at a corner); otherwise it is capped at t >= min(|oc| - r, 1).
+  if (cq > 0.0) {
+    const double r = sqrt(fmax(dot3(oc, oc) - cq, 0.0));
+    float inv = ball_inverse_depth_bound(oc, r);
+    if (!tch) {
+      double front = 1e300;
+      for (int i = 0; i < 4; ++i) {
+        const double c = (i & 1) ? (double)(W - 1) : 0.0, rr = (i & 2) ? (double)(H - 1) : 0.0;
+        front = fmin(front, -(w[0] + c * w[1] + rr * w[2]));
+      }
+      if (!(front > 0.0)) inv = fmaxf(inv, 1.000001f);
+    }
+    out[5] = inv;
+  }
 }
 
 // triangle: for a valid hit (t >= near > 0) sign(n.D) = sign(k), so edge i is satisfied iff
