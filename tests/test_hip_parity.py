@@ -232,3 +232,27 @@ def test_render_views_equals_per_view_render():
         np.testing.assert_array_equal(batch["depth"][i].cpu().numpy(), single["depth"].cpu().numpy())
         np.testing.assert_array_equal(batch["nearest"][i].cpu().numpy(), single["nearest"].cpu().numpy())
     assert np.isfinite(batch["depth"].cpu().numpy()).mean() > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["spheres", "coplanar_discs", "spheres_behind_eye"])
+def test_undecided_pixel_paths_are_bit_identical(kind):
+    """Scenes whose candidates cannot be ranked by the fp32 bound (overlapping spheres, coplanar overlapping splats, the
+    numpy backend's t = 1.0 sentinel for spheres behind the eye): most pixels go through the re-sweep / slow paths,
+    and must still equal the all-pairs fp64 mode bit for bit."""
+    from surf_renderer_amd import synthetic
+    n = 3000
+    scene = synthetic.disk_cloud_scene(n, 256, 256, radius=0.08, seed=11)
+    rng = np.random.RandomState(3)
+    if kind == "coplanar_discs":
+        pos = np.concatenate([rng.uniform(-1, 1, (n, 2)), 1e-4 * rng.normal(size=(n, 1)), np.ones((n, 1))], 1)
+        scene["objects"]["disk"]["pos"] = pos.astype(np.float32)
+        scene["objects"]["disk"]["normal"] = np.tile(np.array([[0, 0, 1, 0]], np.float32), (n, 1))
+    else:
+        d = scene["objects"].pop("disk")
+        pos = d["pos"].copy()
+        if kind == "spheres_behind_eye":
+            pos[: n // 2, 2] += 6.0                    # eye is at z = 4: half of the spheres sit behind it
+        scene["objects"]["sphere"] = {"pos": pos, "radius": d["radius"], "material_idx": d["material_idx"]}
+    ref = _modes_identical(scene, modes=("exact", "binned"))
+    assert np.isfinite(ref["depth"]).mean() > 0.3
