@@ -87,6 +87,17 @@ __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, 
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
+  if (s == 0 && i == 0) {
+    // per-frame fp64 copy of the lights for the fragment stage: position, colour looked up through color_idx
+    double* L = const_cast<double*>(F.lights64);
+    for (int l = 0; l < F.nlights; ++l) {
+      const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+      for (int k = 0; k < 3; ++k) {
+        L[6 * l + k] = (double)F.lpos[4 * l + k];
+        L[6 * l + 3 + k] = (double)F.colors[3 * ci + k];
+      }
+    }
+  }
   if (F.tilerange && F.slab_cull && primitive_misses_slab(F, S, i)) {
     uint16_t* tr = F.tilerange + 4 * (size_t)(S.first + i);
     tr[0] = 1; tr[1] = 0; tr[2] = 0; tr[3] = 0;                   // not binned
@@ -334,7 +345,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t tilerange, tilemask, counters, tile_off, large, entries;
+  size_t lights64, tilerange, tilemask, counters, tile_off, large, entries;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -367,6 +378,8 @@ int check_objects(const SrhObjects* ob) {
 WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   WsLayout L;
   size_t off = 0, total = 0;
+  L.lights64 = off;
+  off = align_up(off + (size_t)SRH_MAX_LIGHTS * 6 * sizeof(double));
   for (int s = 0; s < ob->n_segments; ++s) {
     const SrhSegment& g = ob->seg[s];
     L.off64[s] = off;
@@ -490,6 +503,7 @@ int setup_frame(const SrhCamera* camera, const SrhObjects* objects, const SrhLig
   F.coeffs = materials->coeffs;
   F.normal_out = params->normal_out;
   F.pos_out = params->pos_out;
+  F.lights64 = (const double*)((char*)workspace + L.lights64);
   int first = 0;
   for (int s = 0; s < F.nseg; ++s) {
     const SrhSegment& g = objects->seg[s];

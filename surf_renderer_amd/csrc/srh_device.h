@@ -64,6 +64,7 @@ struct FrameDev {
   uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)
   uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by bin
   SegDev seg[SRH_MAX_SEGMENTS];
+  const double* lights64;            // (nlights,6) per-frame fp64 copy written by k_prep: position xyz, colour rgb
   const float* lpos;
   const int32_t* lcidx;
   const float* colors;
@@ -320,17 +321,21 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
       for (int ch = 0; ch < 3; ++ch)      // the ambient term is added once per light, as the reference does (:116-121)
         im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + (F.ambient ? (double)F.ambient[ch] : 0.0) * alb[ch];
     }
-  } else
-  for (int l = 0; l < F.nlights; ++l) {
-    const float* lp = F.lpos + 4 * l;
-    const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
-    const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-    // |l| <= 0 -> 1 (Q7): the light sits exactly on the fragment and contributes n . 0 = 0
-    const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;
-    const double ndotl = ((n[0] * v[0] + n[1] * v[1]) + n[2] * v[2]) * inv;
-    const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+  } else {
+    // sum_l (n . l^_l) colour_l, times the albedo once at the end (the reference multiplies inside the sum: equal to
+    // ~1e-16, immaterial after the fp32 store); lights come as doubles from the per-frame copy
+    for (int l = 0; l < F.nlights; ++l) {
+      const double* L = F.lights64 + 6 * l;
+      const double v[3] = {L[0] - p[0], L[1] - p[1], L[2] - p[2]};
+      const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+      // |l| <= 0 -> 1 (Q7): the light sits exactly on the fragment and contributes n . 0 = 0
+      const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;
+      const double ndotl = ((n[0] * v[0] + n[1] * v[1]) + n[2] * v[2]) * inv;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) im[ch] += (ndotl * (double)F.colors[3 * ci + ch]) * alb[ch];
+      for (int ch = 0; ch < 3; ++ch) im[ch] += ndotl * L[3 + ch];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) im[ch] *= alb[ch];
   }
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
