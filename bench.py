@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--prims", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="frames in flight: each has its own stream, scratch and output buffers, so the binning "
-                         "kernels of one frame overlap the render kernel of another")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
+                         "overlap the render kernel of another.  0 = 2 on one GPU, 3 on several (a rank's slab leaves "
+                         "the GPU mostly idle; rehearsed with --as-rank)")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
                          "(default), or one gather per frame to rank 0")
@@ -126,7 +127,7 @@ def main():
     #             by one all-to-all (surf_renderer_amd.dist.exchange_frames) -- per frame the same bytes as a gather to
     #             rank 0, but spread over every rank's xGMI links; two batches are buffered so the exchange of one
     #             overlaps the rendering of the next.  (--gather root0: the plain one-gather-per-frame to rank 0.)
-    n_str = max(1, args.inflight)
+    n_str = args.inflight if args.inflight > 0 else (2 if world == 1 and not args.as_rank else 3)
     streams = [torch.cuda.Stream(device) for _ in range(n_str)]
     scratch = [buf.new_workspace(W, H) for _ in range(n_str)]
     equal_slabs = H % world == 0
