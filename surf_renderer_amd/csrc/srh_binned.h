@@ -733,9 +733,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = min(c0 + j, F.W - 1);
-      double dtmp[3];
       Q.cf[j >> 1][j & 1] = (float)c;
-      Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rcpf((float)pixel_ray(F, c, r, dtmp));   // 1.5 ulp: within the estimate's 2^-20
+      // 1 / |D| = rsq(|D|^2): the fp32 conversion (half an ulp of |D|^2) and v_rsq_f32 (1 ulp) together stay below
+      // 1.3 * 2^-23 relative, well inside the 2^-20 the depth estimate reserves (plane_estimate_record)
+      Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rsqf((float)pixel_len2(F, c, r));
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps

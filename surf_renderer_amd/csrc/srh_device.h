@@ -97,6 +97,18 @@ __device__ __forceinline__ double pixel_ray(const FrameDev& F, int c, int r, dou
   return len;
 }
 
+// |D|^2 of the un-normalised direction of pixel (c, r): the part of pixel_ray the fp32 sweep needs (its 1 / |D| comes
+// from one v_rsq_f32 of this, no fp64 square root or division)
+__device__ __forceinline__ double pixel_len2(const FrameDev& F, int c, int r) {
+  const double xs = (F.W > 1 && c == F.W - 1) ? 1.0 : (c * F.step_x + -1.0);
+  const double ys = (F.H > 1 && r == F.H - 1) ? -1.0 : (r * F.step_y + 1.0);
+  const double X = xs * F.half_w, Y = ys * F.half_h, Z = -F.focal;
+  double v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = (F.bx[i] * X + F.by[i] * Y) + F.bz[i] * Z;
+  return (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+}
+
 // ---- intersections: return the reference's ray_distance for one (ray, primitive) pair ------------
 // plane: numpy/renderer.py:53-74
 __device__ __forceinline__ double hit_plane64(const double* R, const double d[3]) {
