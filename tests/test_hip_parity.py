@@ -256,3 +256,13 @@ def test_undecided_pixel_paths_are_bit_identical(kind):
         scene["objects"]["sphere"] = {"pos": pos, "radius": d["radius"], "material_idx": d["material_idx"]}
     ref = _modes_identical(scene, modes=("exact", "binned"))
     assert np.isfinite(ref["depth"]).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_saturated_list_positions_are_bit_identical():
+    """More than 4095 primitives in one tile's lists: key fields saturate and such pixels are resolved by the
+    re-sweep; the result must not change."""
+    from surf_renderer_amd import synthetic
+    scene = synthetic.disk_cloud_scene(6000, 64, 64, radius=0.9, seed=2)      # every disc covers most of the 16 tiles
+    ref = _modes_identical(scene, modes=("exact", "binned"))
+    assert np.isfinite(ref["depth"]).mean() > 0.9
