@@ -58,10 +58,17 @@ def parse():
                          "(default), or one gather per frame to rank 0")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay each frame's kernel sequence (memset, prep, count, scan, fill, render) as one "
-                         "hipGraph per output slot instead of six launches; auto = on, eager if capture fails")
+                         "hipGraph per output slot instead of six launches; auto = on for a single process (eager if "
+                         "capture fails), off when a process group is in use")
     ap.add_argument("--as-rank", default=None, metavar="R/P",
                     help="single-process rehearsal: render only the row slab rank R of a P-rank job would own (no "
                          "collection), to size the per-rank cost of the multi-GPU path on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
+                         "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed loop compare the last collected frame on this rank with a fresh eager render "
+                         "of the same rows (stream / graph / collective ordering self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
     return ap.parse_args()
@@ -103,7 +110,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     from surf_renderer_amd import _lib, renderer, synthetic
@@ -131,7 +141,7 @@ def main():
     streams = [torch.cuda.Stream(device) for _ in range(n_str)]
     scratch = [buf.new_workspace(W, H) for _ in range(n_str)]
     equal_slabs = H % world == 0
-    batched = world > 1 and equal_slabs and args.gather == "alltoall"
+    batched = use_dist and equal_slabs and args.gather == "alltoall"
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
@@ -140,7 +150,10 @@ def main():
     counter = [0]
 
     graphs = {}
-    graph_state = {"on": args.graph != "off", "captured": 0}
+    # Graph replay is used on the single-process path only.  With a process group alive (RCCL kernels and device copies
+    # running beside the replays) the one-rank rehearsal `--force-dist --graph on` ended in a GPU memory fault on
+    # ROCm 7.2, while the same schedule with eager launches runs clean; multi-GPU runs therefore launch eagerly.
+    graph_state = {"on": args.graph == "on" or (args.graph == "auto" and not use_dist), "captured": 0}
 
     def enqueue(key, stream, image, depth, ws, ev):
         """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,
@@ -180,7 +193,6 @@ def main():
         send = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
         recv = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
         pending = [None] * n_bat
-
         def exchange(b):
             for s_ in streams:
                 main.wait_stream(s_)               # every slab of the batch is rendered
@@ -235,7 +247,7 @@ def main():
                 pending[b] = None
             image, depth = views(slabs[b])
             enqueue((b,), streams[b], image, depth, scratch[b], ev)
-            if world > 1:
+            if use_dist:
                 with torch.cuda.stream(streams[b]):
                     pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
 
@@ -245,7 +257,7 @@ def main():
                     pending[b].wait()
                     pending[b] = None
             torch.cuda.synchronize(device)
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -267,10 +279,24 @@ def main():
         step(events[i])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if args.check:
+        ref = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
+        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(*views(ref), None))
+        torch.cuda.synchronize(device)
+        if batched:                                    # my own slab inside the frames assembled on this rank
+            got = [recv[b][rank] for b in range(n_bat) if counter[0] > b * world]
+        else:
+            got = [slabs[b] for b in range(min(n_buf, counter[0]))]
+        for t in got:
+            if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
+                raise SystemExit(f"[bench] rank {rank}: a collected frame differs from the eager render")
+        if rank == 0:
+            print(f"[bench] check ok: {len(got)} collected slab(s) equal the eager render", file=sys.stderr)
 
     kernel_ms = float(np.mean([e.elapsed_ms() for e in events if e is not None]))
     for e in events:
@@ -302,7 +328,7 @@ def main():
                        "launch": f"hipGraph replay ({graph_state['captured']} graphs)" if graph_state["on"] and graphs
                                  else "eager",
                        "parallelism": f"rows/{world}" if not args.as_rank else f"rehearsal of rank {args.as_rank}",
-                       "collection": "none" if world == 1 else
+                       "collection": "none" if not use_dist else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -322,7 +348,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
