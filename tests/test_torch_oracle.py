@@ -75,3 +75,41 @@ def test_gradients_are_consistent_with_finite_differences():
             vals.append(loss(sc))
         fd = (vals[0] - vals[1]) / (2 * eps)
         np.testing.assert_allclose(grads[key][idx], fd, rtol=2e-5, atol=1e-7, err_msg=f"{key}{idx}")
+
+
+@pytest.mark.parametrize("case", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic"])
+def test_phong_autograd_matches_reference_torch_backend(case):
+    """Torch-backend semantics (attenuation, specular, ambient, per-light relu, double_sided, use_quartic): the fp64
+    gradient oracle against what the reference's torch backend produced under autograd (float32).  The reference's
+    sphere gradients are NaN (sqrt under a mask, torch/utils.py:238-279), so the sphere leaves are not compared."""
+    import json
+    npz = np.load(os.path.join(GOLDEN_DIR, case + ".npz"), allow_pickle=False)
+    scene = unpack_scene(npz)
+    kw = json.loads(str(npz["kwargs"]))
+    leaves = torch_oracle.make_leaves_tch(scene, requires_grad=False)
+    image, depth, hit = torch_oracle.render_tch(scene, leaves, **kw)
+    assert bool(hit.all())
+    same = np.asarray(npz["ref/nearest"]) == np.asarray(__import__("oracle.np_oracle_tch", fromlist=["x"]).render(scene, **kw)["nearest"])
+    assert same.mean() > 0.995
+    np.testing.assert_allclose(image.numpy()[same], npz["ref/image"][same], atol=3e-4)
+    np.testing.assert_allclose(depth.numpy()[same], npz["ref/depth"][same], rtol=2e-5)
+    grads = torch_oracle.gradients_tch(scene, npz["grad_in/image"].astype(np.float64),
+                                       npz["grad_in/depth"].astype(np.float64), **kw)
+    checked = 0
+    for key in npz.files:
+        if not key.startswith("grad/") or key.startswith("grad/sphere."):
+            continue
+        name = key[5:]
+        want = npz[key].astype(np.float64)
+        got = grads[name]
+        if name == "lights.pos":
+            got, want = got[:, :3], want[:, :3]
+        if name in ("plane.pos", "disk.pos"):
+            got, want = got[:, :3], want[:, :3]
+        scale = max(np.abs(want).max(), 1e-6)
+        # float32 reference, a handful of silhouette pixels decided differently: 1 % of the largest entry
+        np.testing.assert_allclose(got, want, atol=1e-2 * scale, err_msg=name)
+        checked += 1
+    assert checked == 13
+    assert np.isnan(npz["grad/sphere.pos"]).any()                  # documents why spheres are left out
+    assert np.all(np.isfinite(grads["sphere.pos"])) and np.abs(grads["sphere.pos"]).max() > 0
