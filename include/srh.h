@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 1
+#define SRH_ABI_VERSION 2
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -163,6 +163,9 @@ typedef struct SrhGrads {
   float* lights_pos;                 /* (n_lights,4) */
   float* colors;                     /* (n_colors,3) */
   float* albedo;                     /* (n_materials,3) */
+  float* coeffs;                     /* (n_materials,3) SRH_SHADING_TORCH only: material coefficients (c0, c1, c2) */
+  float* attenuation;                /* (n_lights,3)    SRH_SHADING_TORCH only: (kc, kl, kq) */
+  float* ambient;                    /* (3)             SRH_SHADING_TORCH only */
 } SrhGrads;
 
 /* Analytic backward of srh_render_fwd: the vector-Jacobian product of (image, depth) w.r.t. the scene arrays for the
@@ -170,8 +173,10 @@ typedef struct SrhGrads {
  * forward pass (`nearest`, and `depth` to tell hit pixels from background).  Defined exactly as autograd through
  * the reference's differentiable backend defines it (diffrend/torch/renderer.py:136-355, torch/utils.py:238-366):
  * the nearest-hit selection and all masks are piecewise constant, so gradients flow only through the winner's hit
- * distance, hit point, normal, albedo and the lights.  Row strides and the row range come from `params` as in the
- * forward call. */
+ * distance, hit point, normal, albedo and the lights.  With SRH_SHADING_TORCH the shading model differentiated is that
+ * backend's Phong model (attenuation, specular coefficients, ambient; relus, the double_sided sign and the masks are
+ * constants), and coeffs / attenuation / ambient gradients are available.  Row strides and the row range come from
+ * `params` as in the forward call. */
 int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
                    const SrhMaterials* materials, const SrhParams* params,
                    void* workspace, size_t workspace_bytes,

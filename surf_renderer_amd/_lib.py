@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -60,7 +60,8 @@ class SrhParams(C.Structure):
 class SrhGrads(C.Structure):
     _fields_ = [("pos", C.c_void_p * MAX_SEGMENTS), ("normal", C.c_void_p * MAX_SEGMENTS),
                 ("radius", C.c_void_p * MAX_SEGMENTS), ("face", C.c_void_p * MAX_SEGMENTS),
-                ("lights_pos", C.c_void_p), ("colors", C.c_void_p), ("albedo", C.c_void_p)]
+                ("lights_pos", C.c_void_p), ("colors", C.c_void_p), ("albedo", C.c_void_p),
+                ("coeffs", C.c_void_p), ("attenuation", C.c_void_p), ("ambient", C.c_void_p)]
 
 
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",

@@ -650,8 +650,6 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (rc) return rc;
   if (!grad_image || !nearest || !depth || !grads)
     return fail(SRH_E_NULL, "grad_image / nearest / depth / grads is NULL");
-  if (params->shading != SRH_SHADING_NUMPY)
-    return fail(SRH_E_TYPE, "the analytic backward covers SRH_SHADING_NUMPY only");
   GradsDev G;
   for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) {
     G.pos[s] = grads->pos[s]; G.normal[s] = grads->normal[s]; G.radius[s] = grads->radius[s]; G.face[s] = grads->face[s];
@@ -659,6 +657,10 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   G.lights_pos = grads->lights_pos;
   G.colors = grads->colors;
   G.albedo = grads->albedo;
+  const bool tch = params->shading == SRH_SHADING_TORCH;
+  G.coeffs = tch ? grads->coeffs : nullptr;
+  G.attenuation = tch ? grads->attenuation : nullptr;
+  G.ambient = tch ? grads->ambient : nullptr;
   hipStream_t st = (hipStream_t)stream;
   // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
   for (int s = 0; s < F.nseg; ++s) {
@@ -668,7 +670,8 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
-  hipLaunchKernelGGL(k_render_bwd, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
+  if (tch) hipLaunchKernelGGL(k_render_bwd_tch, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
+  else hipLaunchKernelGGL(k_render_bwd, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
   if (params->ev_stop) (void)hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "backward launch");

@@ -22,6 +22,9 @@ struct GradsDev {
   float* lights_pos;
   float* colors;
   float* albedo;
+  float* coeffs;        // torch shading only
+  float* attenuation;   // torch shading only
+  float* ambient;       // torch shading only
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -245,6 +248,309 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
   const double nin2 = (((double)np_[0] * np_[0] + (double)np_[1] * np_[1]) + (double)np_[2] * np_[2]) + (double)np_[3] * np_[3];
   const double ninv = (nin2 > 0.0) ? 1.0 / sqrt(nin2) : 1.0;
   const double proj = (nin2 > 0.0) ? (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2] : 0.0;
+  double g_nin[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g_nin[k] = (g_nh[k] - n[k] * proj) * ninv;
+  if (type == SRH_PRIM_TRIANGLE) {
+    if (G.face[s]) add3(G.face[s] + 12 * (size_t)li, g_q);
+  } else if (G.pos[s]) {
+    add3(G.pos[s] + 4 * (size_t)li, g_q);
+  }
+  if (G.normal[s]) add3(G.normal[s] + 4 * (size_t)li, g_nin);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the torch backend's semantics (SRH_SHADING_TORCH; reference torch/renderer.py:82-125,136-355):
+//     n^ = n / sqrt(|n|^2 + 3e-10)  (sphere: (p - c) likewise),   c^ = (o - p) / sqrt(|o - p|^2 + 3e-10)
+//     per light i:  l = L_i - p, dist = |l|, l^ = l / dist,  afac = 1 / (kc + kl dist + kq dist^pw)   (pw = 2 | 4)
+//                   ndotl = relu(sgn afac (l^ . n^)),  rdotc = relu(sgn (2 (l^ . n^)(c^ . n^) - c^ . l^))
+//                   im_c += (c0 ndotl + c1 rdotc^c2) C_ic A_c + amb_c A_c
+//     out_c = relu(im_c) ^ gamma
+// sgn = sign(c^ . n^) with double_sided, else 1 -- a constant, like the relus (threshold_backward selects, it does not
+// multiply) and the nearest-hit selection.  torch.pow: 0^0 = 1, d/d exponent = 0 at base 0, d/d base = 0 at exponent 0.
+// Misses and the far + 1 background carry no gradient.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
+                                                         const float* __restrict__ grad_depth,
+                                                         const int32_t* __restrict__ nearest,
+                                                         const float* __restrict__ depth) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r = F.row0 + blockIdx.y * 4 + threadIdx.y;
+  const int lane = threadIdx.x;
+  const bool live = (c < F.W) && (r < F.row1);
+  const size_t row = live ? (size_t)(r - F.row0) : 0;
+  const int cc = live ? c : 0;
+  const bool hit = live && ((double)depth[row * F.depth_stride + cc] <= F.far_clip);
+
+  double g_out[3] = {0, 0, 0}, g_dep = 0.0;
+  int win = 0;
+  if (hit) {
+    const float* gi = grad_image + row * F.img_stride + 3 * (size_t)cc;
+    g_out[0] = gi[0]; g_out[1] = gi[1]; g_out[2] = gi[2];
+    if (grad_depth) g_dep = grad_depth[row * F.depth_stride + cc];
+    win = nearest[row * F.near_stride + cc];
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+    if (i < F.nseg && win >= F.seg[i].first) s = i;
+  int type = F.seg[0].type, first = F.seg[0].first;
+  const double* rec_base = F.seg[0].rec64;
+  const float* pos_base = F.seg[0].pos;
+  const float* nrm_base = F.seg[0].normal;
+  const float* rad_base = F.seg[0].radius;
+  const float* face_base = F.seg[0].face;
+  const int32_t* mat_base = F.seg[0].mat;
+#pragma unroll
+  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+    if (s == i) {
+      type = F.seg[i].type; first = F.seg[i].first; rec_base = F.seg[i].rec64; pos_base = F.seg[i].pos;
+      nrm_base = F.seg[i].normal; rad_base = F.seg[i].radius; face_base = F.seg[i].face; mat_base = F.seg[i].mat;
+    }
+  const int li = win - first;
+
+  double d[3] = {0, 0, -1};
+  pixel_ray(F, live ? c : 0, live ? r : F.row0, d);
+
+  // ---- forward quantities of this pixel ---------------------------------------------------------------------
+  double t = 0.0, n[3] = {0, 0, 0}, p[3] = {0, 0, 0};
+  double sph_inv = 0.0;                                    // sphere: 1 / sqrt(|p - c|^2 + 3e-10)
+  const double* R = rec_base + (size_t)li * kRec64Stride[type];
+  if (hit) {
+    t = hit_any64(type, R, F.o, d, true);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = F.o[k] + t * d[k];
+    if (type == SRH_PRIM_SPHERE) {
+      const float* cp = pos_base + 4 * (size_t)li;
+      double v[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = p[k] - (double)cp[k];
+      sph_inv = 1.0 / sqrt(((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + 3.0e-10);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) n[k] = v[k] * sph_inv;
+    } else {
+      n[0] = R[0]; n[1] = R[1]; n[2] = R[2];
+    }
+  }
+  const int m = hit ? clampi(mat_base[li], 0, F.nmat - 1) : 0;
+  double alb[3] = {0, 0, 0}, cf[3] = {1.0, 0.0, 0.0}, amb[3] = {0, 0, 0};
+  if (hit) {
+    alb[0] = F.albedo[3 * m]; alb[1] = F.albedo[3 * m + 1]; alb[2] = F.albedo[3 * m + 2];
+    if (F.coeffs) { cf[0] = F.coeffs[3 * m]; cf[1] = F.coeffs[3 * m + 1]; cf[2] = F.coeffs[3 * m + 2]; }
+    if (F.ambient) { amb[0] = F.ambient[0]; amb[1] = F.ambient[1]; amb[2] = F.ambient[2]; }
+  }
+  // view direction
+  const double u[3] = {F.o[0] - p[0], F.o[1] - p[1], F.o[2] - p[2]};
+  const double sc_inv = 1.0 / sqrt(((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]) + 3.0e-10);
+  const double cdir[3] = {u[0] * sc_inv, u[1] * sc_inv, u[2] * sc_inv};
+  const double cdotn = (cdir[0] * n[0] + cdir[1] * n[1]) + cdir[2] * n[2];
+  const double sgn = F.double_sided ? ((cdotn > 0.0) ? 1.0 : ((cdotn < 0.0) ? -1.0 : 0.0)) : 1.0;
+  const int pw = F.use_quartic ? 4 : 2;
+
+  // per-light forward terms, evaluated twice (image first: its value gates the clip / tonemap derivative)
+  struct LightTerms {
+    double lh[3], dist, afac, ldn, nd, rd, cl;
+    bool nz, den_ok;
+  };
+  auto light_terms = [&](int l, LightTerms& T) {
+    const float* lp = F.lpos + 4 * l;
+    const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
+    T.dist = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    T.nz = T.dist > 0.0;
+    const double inv = T.nz ? 1.0 / T.dist : 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T.lh[k] = v[k] * inv;
+    const double kc = F.latt ? (double)F.latt[3 * l] : 1.0, kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0,
+                 kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
+    const double dp = (pw == 4) ? (T.dist * T.dist) * (T.dist * T.dist) : T.dist * T.dist;
+    const double den = (kc + T.dist * kl) + dp * kq;
+    T.den_ok = fabs(den) > 0.0;
+    T.afac = T.den_ok ? 1.0 / den : 1.0;
+    T.ldn = (T.lh[0] * n[0] + T.lh[1] * n[1]) + T.lh[2] * n[2];
+    T.cl = (cdir[0] * T.lh[0] + cdir[1] * T.lh[1]) + cdir[2] * T.lh[2];
+    T.nd = sgn * (T.afac * T.ldn);
+    T.rd = sgn * (2.0 * T.ldn * cdotn - T.cl);
+  };
+  auto spec_pow = [&](double rdotc) { return (rdotc == 0.0 && cf[2] == 0.0) ? 1.0 : pow(rdotc, cf[2]); };
+
+  double im[3] = {0, 0, 0};
+  for (int l = 0; l < F.nlights; ++l) {
+    LightTerms T;
+    light_terms(l, T);
+    const double w = cf[0] * fmax(T.nd, 0.0) + cf[1] * spec_pow(fmax(T.rd, 0.0));
+    const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + amb[ch] * alb[ch];
+  }
+  double g_im[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    double w = 0.0;
+    if (hit && im[ch] > 0.0) w = F.tonemap ? F.gamma * pow(im[ch], F.gamma - 1.0) : 1.0;
+    g_im[ch] = g_out[ch] * w;
+  }
+
+  double g_n[3] = {0, 0, 0}, g_p[3] = {0, 0, 0}, g_alb[3] = {0, 0, 0}, g_cf[3] = {0, 0, 0}, g_amb[3] = {0, 0, 0};
+  double g_cdir[3] = {0, 0, 0}, g_cdotn = 0.0;
+  for (int l = 0; l < F.nlights; ++l) {
+    LightTerms T;
+    light_terms(l, T);
+    const double ndotl = fmax(T.nd, 0.0), rdotc = fmax(T.rd, 0.0);
+    const double P = spec_pow(rdotc);
+    const double w = cf[0] * ndotl + cf[1] * P;
+    const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
+    double g_w = 0.0, g_col[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const double col = (double)F.colors[3 * ci + ch];
+      g_w += g_im[ch] * col * alb[ch];
+      g_alb[ch] += g_im[ch] * (w * col + amb[ch]);
+      g_col[ch] = g_im[ch] * w * alb[ch];
+      g_amb[ch] += g_im[ch] * alb[ch];
+    }
+    g_cf[0] += g_w * ndotl;
+    g_cf[1] += g_w * P;
+    if (rdotc > 0.0) g_cf[2] += g_w * cf[1] * P * log(rdotc);
+    const double g_nd = (T.nd > 0.0) ? g_w * cf[0] : 0.0;
+    const double g_rd = (T.rd > 0.0 && cf[2] != 0.0) ? g_w * cf[1] * cf[2] * pow(rdotc, cf[2] - 1.0) : 0.0;
+    double g_ldn = g_rd * sgn * 2.0 * cdotn + g_nd * sgn * T.afac;
+    g_cdotn += g_rd * sgn * 2.0 * T.ldn;
+    const double g_cl = -g_rd * sgn;
+    const double g_afac = g_nd * sgn * T.ldn;
+    const double g_den = T.den_ok ? -g_afac * T.afac * T.afac : 0.0;
+    const double kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0, kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
+    const double d2 = T.dist * T.dist;
+    const double dp = (pw == 4) ? d2 * d2 : d2;
+    const double ddp = (pw == 4) ? 4.0 * d2 * T.dist : 2.0 * T.dist;
+    const double g_dist = g_den * (kl + kq * ddp);
+    double g_lh[3], g_v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g_lh[k] = g_ldn * n[k] + g_cl * cdir[k];
+      g_n[k] += g_ldn * T.lh[k];
+      g_cdir[k] += g_cl * T.lh[k];
+    }
+    const double proj = (T.lh[0] * g_lh[0] + T.lh[1] * g_lh[1]) + T.lh[2] * g_lh[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g_v[k] = T.nz ? (g_lh[k] - T.lh[k] * proj) / T.dist + g_dist * T.lh[k] : g_lh[k];
+      g_p[k] -= g_v[k];
+    }
+    if (G.lights_pos) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float sum = wave_sum((float)g_v[k]);
+        if (lane == 0 && sum != 0.0f) atomicAdd(G.lights_pos + 4 * l + k, sum);
+      }
+    }
+    if (G.colors) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float sum = wave_sum((float)g_col[ch]);
+        if (lane == 0 && sum != 0.0f) atomicAdd(G.colors + 3 * ci + ch, sum);
+      }
+    }
+    if (G.attenuation) {
+      const double ga[3] = {g_den, g_den * T.dist, g_den * dp};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float sum = wave_sum((float)ga[k]);
+        if (lane == 0 && sum != 0.0f) atomicAdd(G.attenuation + 3 * l + k, sum);
+      }
+    }
+  }
+  if (G.ambient) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float sum = wave_sum((float)g_amb[ch]);
+      if (lane == 0 && sum != 0.0f) atomicAdd(G.ambient + ch, sum);
+    }
+  }
+  {
+    // one material for the whole wave (the common case) -> one atomic per component; otherwise per lane
+    const int m0 = __builtin_amdgcn_readfirstlane(m);
+    const bool uniform = __builtin_amdgcn_ballot_w64(hit && m != m0) == 0ull;
+    if (G.albedo) {
+      if (uniform) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float sum = wave_sum((float)g_alb[ch]);
+          if (lane == 0 && sum != 0.0f) atomicAdd(G.albedo + 3 * m0 + ch, sum);
+        }
+      } else if (hit) {
+        add3(G.albedo + 3 * m, g_alb);
+      }
+    }
+    if (G.coeffs) {
+      if (uniform) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float sum = wave_sum((float)g_cf[k]);
+          if (lane == 0 && sum != 0.0f) atomicAdd(G.coeffs + 3 * m0 + k, sum);
+        }
+      } else if (hit) {
+        add3(G.coeffs + 3 * m, g_cf);
+      }
+    }
+  }
+  if (!hit) return;                                     // no shuffles below this line
+
+  // c^ . n^ and c^ = u / sqrt(|u|^2 + eps), u = o - p
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { g_cdir[k] += g_cdotn * n[k]; g_n[k] += g_cdotn * cdir[k]; }
+  {
+    const double proj = (cdir[0] * g_cdir[0] + cdir[1] * g_cdir[1]) + cdir[2] * g_cdir[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_p[k] -= (g_cdir[k] - cdir[k] * proj) * sc_inv;
+  }
+
+  // ---- geometry ------------------------------------------------------------------------------------------------
+  if (type == SRH_PRIM_SPHERE) {
+    const double proj = (n[0] * g_n[0] + n[1] * g_n[1]) + n[2] * g_n[2];
+    double g_c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double g_v = (g_n[k] - n[k] * proj) * sph_inv;
+      g_p[k] += g_v;
+      g_c[k] = -g_v;
+    }
+    const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
+    const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    const double b = 2.0 * dot3(R, d);
+    const double disc = b * b - 4.0 * a * R[3];
+    double g_r = 0.0;
+    if (disc > 0.0) {
+      const double root = sqrt(disc), inv2a = 1.0 / (2.0 * a);
+      const double t1 = (-b - root) * inv2a;
+      const double sg = (t1 >= 0.0) ? -1.0 : 1.0;       // the smaller non-negative root
+      double g_b = -g_t * inv2a;
+      const double g_disc = sg * g_t * inv2a / (2.0 * root);
+      g_b += 2.0 * b * g_disc;
+      const double g_cc = -4.0 * a * g_disc;
+      g_r = -2.0 * (double)rad_base[li] * g_cc;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g_c[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
+    }
+    if (G.pos[s]) add3(G.pos[s] + 4 * (size_t)li, g_c);
+    if (G.radius[s] && g_r != 0.0) atomicAdd(G.radius[s] + li, (float)g_r);
+    return;
+  }
+  // planar: t = k/den, k = n^.(q - o), den = n^.d
+  const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
+  const double den = dot3(R, d);
+  const double g_k = g_t / den, g_den = -g_t * t / den;
+  const float* qp = (type == SRH_PRIM_TRIANGLE) ? face_base + 12 * (size_t)li : pos_base + 4 * (size_t)li;
+  double g_q[3], g_nh[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    g_q[k] = g_k * n[k];
+    g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
+  }
+  // n^ = nin / sqrt(|nin|^2 + 3e-10) over xyz
+  const float* np_ = nrm_base + 4 * (size_t)li;
+  const double nin2 = (((double)np_[0] * np_[0] + 1e-10) + ((double)np_[1] * np_[1] + 1e-10)) + ((double)np_[2] * np_[2] + 1e-10);
+  const double ninv = 1.0 / sqrt(nin2);
+  const double proj = (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2];
   double g_nin[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) g_nin[k] = (g_nh[k] - n[k] * proj) * ninv;

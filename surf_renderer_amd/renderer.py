@@ -182,17 +182,17 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
     ms = _lib.SrhMaterials(n_materials=albedo.shape[0], albedo=albedo.data_ptr())
     # inputs of the torch backend's shading model only (ignored by the numpy one, numpy/renderer.py:234-255)
     if "attenuation" in lights:
-        att = _as_tensor(lights["attenuation"], f32, device).reshape(-1, 3)
+        att = _as_tensor(lights["attenuation"], f32, device, keep_graph).reshape(-1, 3)
         if att.shape[0] != lpos.shape[0]:
             raise ValueError("lights.attenuation must have one (kc, kl, kq) row per light")
         tensors["lights.attenuation"] = att
         ls.attenuation = att.data_ptr()
     if "ambient" in lights:
-        amb = _as_tensor(lights["ambient"], f32, device).reshape(3)
+        amb = _as_tensor(lights["ambient"], f32, device, keep_graph).reshape(3)
         tensors["lights.ambient"] = amb
         ls.ambient = amb.data_ptr()
     if "coeffs" in scene["materials"]:
-        cfs = _as_tensor(scene["materials"]["coeffs"], f32, device).reshape(-1, 3)
+        cfs = _as_tensor(scene["materials"]["coeffs"], f32, device, keep_graph).reshape(-1, 3)
         if cfs.shape[0] != albedo.shape[0]:
             raise ValueError("materials.coeffs must have one row per material")
         tensors["materials.coeffs"] = cfs
@@ -328,10 +328,17 @@ def generate_rays(camera: Dict[str, Any], device="cuda", rows: Optional[Tuple[in
     return out
 
 
-def _float_keys(buf: SceneBuffers) -> List[str]:
-    """Keys of buf.tensors that are differentiable inputs, in a fixed order."""
+_TORCH_SHADING_KEYS = ("materials.coeffs", "lights.attenuation", "lights.ambient")
+
+
+def _float_keys(buf: SceneBuffers, shading: str = "numpy") -> List[str]:
+    """Keys of buf.tensors that are differentiable inputs, in a fixed order (the torch shading model adds its own
+    inputs where the scene has them)."""
     keys = [f"{kind}.{name}" for kind in buf.kinds for name in _OBJ_FIELDS[kind]]
-    return keys + ["lights.pos", "colors", "materials.albedo"]
+    keys += ["lights.pos", "colors", "materials.albedo"]
+    if shading == "torch":
+        keys += [k for k in _TORCH_SHADING_KEYS if k in buf.tensors]
+    return keys
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -340,9 +347,11 @@ class _RenderFunction(torch.autograd.Function):
     constant; a disc's radius and a triangle's vertices 1, 2 receive zero gradient."""
 
     @staticmethod
-    def forward(ctx, buf, cam, rows, mode, *inputs):
-        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode)
-        ctx.buf, ctx.cam, ctx.rows, ctx.mode = buf, cam, rows, mode
+    def forward(ctx, buf, cam, rows, mode, shade, *inputs):
+        # shade = (shading, double_sided, use_quartic)
+        image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode, shading=shade[0],
+                                               double_sided=shade[1], use_quartic=shade[2])
+        ctx.buf, ctx.cam, ctx.rows, ctx.mode, ctx.shade = buf, cam, rows, mode, shade
         ctx.save_for_backward(depth, nearest)
         ctx.mark_non_differentiable(nearest)
         return image, depth, nearest
@@ -354,8 +363,8 @@ class _RenderFunction(torch.autograd.Function):
         lib = _lib.load()
         width, height = frame_size(cam)
         r0, r1 = (0, height) if ctx.rows is None else (int(ctx.rows[0]), int(ctx.rows[1]))
-        keys = _float_keys(buf)
-        need = ctx.needs_input_grad[4:]
+        keys = _float_keys(buf, ctx.shade[0])
+        need = ctx.needs_input_grad[5:]
         grads: Dict[str, torch.Tensor] = {}
         sg = _lib.SrhGrads()
         for key, want in zip(keys, need):
@@ -369,6 +378,12 @@ class _RenderFunction(torch.autograd.Function):
                 sg.colors = g.data_ptr()
             elif key == "materials.albedo":
                 sg.albedo = g.data_ptr()
+            elif key == "materials.coeffs":
+                sg.coeffs = g.data_ptr()
+            elif key == "lights.attenuation":
+                sg.attenuation = g.data_ptr()
+            elif key == "lights.ambient":
+                sg.ambient = g.data_ptr()
             else:
                 kind, name = key.split(".")
                 s = buf.kinds.index(kind)
@@ -380,7 +395,9 @@ class _RenderFunction(torch.autograd.Function):
         g_depth = g_depth.to(torch.float32).contiguous() if g_depth is not None else None
         params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[ctx.mode],
                                 tonemap_gamma=0 if buf.gamma is None else 1,
-                                gamma=1.0 if buf.gamma is None else buf.gamma)
+                                gamma=1.0 if buf.gamma is None else buf.gamma,
+                                shading=_lib.SHADING[ctx.shade[0]], double_sided=int(bool(ctx.shade[1])),
+                                use_quartic=int(bool(ctx.shade[2])))
         workspace = buf.ensure_workspace(width, height)
         with torch.cuda.device(buf.device):
             rc = lib.srh_render_bwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
@@ -388,7 +405,7 @@ class _RenderFunction(torch.autograd.Function):
                                     g_image.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
                                     nearest.data_ptr(), depth.data_ptr(), C.byref(sg), _stream_ptr(buf.device))
         _lib.check(rc)
-        return (None, None, None, None) + tuple(grads.get(k) for k in keys)
+        return (None, None, None, None, None) + tuple(grads.get(k) for k in keys)
 
 
 def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], device="cuda", mode: str = "auto",
@@ -480,11 +497,14 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
         raise ValueError(f"shading must be 'numpy' or 'torch', got {shading!r}")
     if params.get("shadow"):
         raise NotImplementedError("shadow rays (torch/renderer.py:291-314) are not implemented by the hip backend")
-    inputs = [buf.tensors[k] for k in _float_keys(buf)]
+    inputs = [buf.tensors[k] for k in _float_keys(buf, shading)]
     if shading == "torch":
-        # the torch backend's semantics: forward only
+        # the torch backend's semantics
+        shade = ("torch", bool(params.get("double_sided", False)), bool(params.get("use_quartic", False)))
         if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
-            raise NotImplementedError("shading='torch' has no analytic backward yet; use shading='numpy'")
+            # differentiable call (no normal / pos outputs on this path)
+            image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, shade, *inputs)
+            return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64))
         width, height = frame_size(cam)
         r0, r1 = (0, height) if rows is None else rows
         normal = torch.empty((r1 - r0, width, 3), dtype=torch.float32, device=device)
@@ -497,7 +517,7 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
                             normal=normal, pos=pos)
     if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
         # differentiable call: image and depth carry a grad_fn backed by the analytic HIP backward
-        image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, *inputs)
+        image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, ("numpy", False, False), *inputs)
     else:
         image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode,
                                                waves_per_tile=params.get("waves_per_tile", 0))

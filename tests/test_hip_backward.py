@@ -112,3 +112,79 @@ def test_backward_disk_cloud_and_no_grad_inputs():
     assert sc["materials"]["albedo"].grad is not None and sc["materials"]["albedo"].grad.abs().max() > 0
     with torch.no_grad():
         assert not render(sc, device="cuda:0")["image"].requires_grad
+
+
+def _torch_shading_scene(name):
+    """Scenes with the torch backend's extra inputs: the reference-pinned gradient fixture (all four primitive
+    types, specular materials, ambient, three attenuation laws), and a disc cloud lit from both sides."""
+    import json
+    if name.startswith("g10"):
+        npz = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        from oracle.golden_io import unpack_scene
+        return unpack_scene(npz), json.loads(str(npz["kwargs"]))
+    from surf_renderer_amd import synthetic
+    from surf_renderer_amd.scene import scene_to_numpy
+    sc = scene_to_numpy(synthetic.disk_cloud_scene(400, 64, 48, radius=0.12, seed=4), round_fp32=True)
+    nrm = sc["objects"]["disk"]["normal"].copy()
+    nrm[::2] *= -1.0
+    sc["objects"]["disk"]["normal"] = nrm
+    sc["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01], [1, 0, 0.02], [0.3, 0.2, 0]], dtype=np.float64)
+    sc["lights"]["ambient"] = np.array([0.02, 0.01, 0.03])
+    sc["materials"]["coeffs"] = np.array([[0.8, 0.2, 5.0]])
+    return sc, {"double_sided": True}
+
+
+def _leaf_scene_tch(scene):
+    """Copy of the scene whose differentiable arrays (incl. coeffs / attenuation / ambient) are GPU leaves."""
+    import copy
+    sc = copy.deepcopy(scene)
+    leaves = {}
+
+    def leaf(arr):
+        return torch.tensor(np.asarray(arr, dtype=np.float32), device="cuda:0", requires_grad=True)
+
+    for kind, grp in sc["objects"].items():
+        for name in torch_oracle.LEAF_KEYS[kind]:
+            grp[name] = leaves[f"{kind}.{name}"] = leaf(grp[name])
+    sc["lights"]["pos"] = leaves["lights.pos"] = leaf(sc["lights"]["pos"])
+    sc["lights"]["attenuation"] = leaves["lights.attenuation"] = leaf(sc["lights"]["attenuation"])
+    sc["lights"]["ambient"] = leaves["lights.ambient"] = leaf(sc["lights"]["ambient"])
+    sc["colors"] = leaves["colors"] = leaf(sc["colors"])
+    sc["materials"]["albedo"] = leaves["materials.albedo"] = leaf(sc["materials"]["albedo"])
+    sc["materials"]["coeffs"] = leaves["materials.coeffs"] = leaf(sc["materials"]["coeffs"])
+    return sc, leaves
+
+
+@pytest.mark.parametrize("name", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic", "cloud_ds"])
+def test_torch_shading_backward_matches_gradient_oracle(name):
+    """render(scene, shading='torch') under autograd: the analytic HIP backward of the Phong model against the fp64
+    gradient oracle (itself pinned by the reference's torch autograd, tests/test_torch_oracle.py)."""
+    from oracle import np_oracle_tch
+    scene, kw = _torch_shading_scene(name)
+    ref = np_oracle_tch.render(scene, **kw)
+    H, W = ref["depth"].shape
+    rng = np.random.RandomState(5)
+    g_img = rng.uniform(-1, 1, size=(H, W, 3))
+    g_dep = rng.uniform(-1, 1, size=(H, W))
+
+    from surf_renderer_amd import render
+    leaf_scene, leaves = _leaf_scene_tch(scene)
+    res = render(leaf_scene, device="cuda:0", shading="torch", **kw)
+    same = res["nearest"].cpu().numpy() == ref["nearest"]
+    hit = ref["depth"] <= scene["camera"]["far"]
+    assert (same | ~hit).mean() > 0.999
+    far = float(scene["camera"]["far"])
+    dep = res["depth"]
+    loss = torch.sum(res["image"] * torch.as_tensor(g_img, dtype=torch.float32, device=dep.device)) + \
+        torch.sum(torch.where(dep <= far, dep * torch.as_tensor(g_dep, dtype=torch.float32, device=dep.device),
+                              torch.zeros_like(dep)))
+    loss.backward()
+    want = torch_oracle.gradients_tch(scene, g_img, g_dep, ref=ref, **kw)
+    checked = 0
+    for key, t in leaves.items():
+        got = t.grad.cpu().numpy().astype(np.float64) if t.grad is not None else np.zeros(tuple(t.shape))
+        w = want[key].reshape(got.shape)
+        scale = max(np.abs(w).max(), 1e-9)
+        np.testing.assert_allclose(got, w, atol=2e-4 * scale + 1e-6, err_msg=key)
+        checked += 1
+    assert checked >= 9
