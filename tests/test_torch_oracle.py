@@ -113,3 +113,38 @@ def test_phong_autograd_matches_reference_torch_backend(case):
     assert checked == 13
     assert np.isnan(npz["grad/sphere.pos"]).any()                  # documents why spheres are left out
     assert np.all(np.isfinite(grads["sphere.pos"])) and np.abs(grads["sphere.pos"]).max() > 0
+
+
+def test_phong_gradients_are_consistent_with_finite_differences():
+    """The torch-semantics oracle's autograd against central differences of its own forward, in particular for the
+    sphere leaves, which the reference fixture cannot pin (its sphere gradients are NaN)."""
+    import copy
+    from oracle import np_oracle_tch
+    npz = np.load(os.path.join(GOLDEN_DIR, "g10_torch_autograd_phong.npz"), allow_pickle=False)
+    scene = unpack_scene(npz)
+    ref = np_oracle_tch.render(scene)
+    rng = np.random.RandomState(1)
+    g_img = rng.uniform(-1, 1, size=ref["image"].shape)
+    grads = torch_oracle.gradients_tch(scene, g_img, ref=ref)
+
+    def loss(sc):
+        leaves = torch_oracle.make_leaves_tch(sc, requires_grad=False)
+        image, _, _ = torch_oracle.render_tch(sc, leaves, ref=ref)
+        return float(torch.sum(image * torch.as_tensor(g_img)))
+
+    def target(sc, key):
+        a, b = key.split(".")
+        return sc["objects"][a][b] if a in sc["objects"] else sc[a][b]
+
+    for key, idx in (("sphere.pos", (0, 1)), ("sphere.pos", (1, 2)), ("sphere.radius", (0,)), ("sphere.radius", (1,)),
+                     ("materials.coeffs", (1, 0)), ("materials.coeffs", (2, 1)), ("materials.coeffs", (1, 2)),
+                     ("lights.attenuation", (1, 1)), ("lights.attenuation", (2, 2)), ("lights.ambient", (1,)),
+                     ("disk.normal", (0, 1)), ("plane.pos", (0, 2)), ("lights.pos", (0, 0))):
+        eps = 1e-6
+        vals = []
+        for sign in (+1, -1):
+            sc = copy.deepcopy(scene)
+            target(sc, key)[idx] += sign * eps
+            vals.append(loss(sc))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        np.testing.assert_allclose(grads[key][idx], fd, rtol=5e-5, atol=2e-7, err_msg=f"{key}{idx}")
