@@ -210,12 +210,12 @@ __device__ __forceinline__ void store_aux(const FrameDev& F, size_t row, int c, 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// 1/sqrt(x) for x > 0 to ~1 ulp of fp64 without the IEEE sqrt + divide expansions: v_rsq_f64 seed and two
-// Newton steps.  Only the fragment stage uses it; its result is rounded to fp32 on output.
+// 1/sqrt(x) for x > 0 without the IEEE sqrt + divide expansions: v_rsq_f64 seed (about 26 bits) and one Newton step
+// (about 50 bits).  Only the fragment stage uses it; its result is rounded to fp32 on output.
 __device__ __forceinline__ double rsqrt_newton(double x) {
   double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < 1; ++it) {
     const double e = __builtin_fma(-x * y, y, 1.0);
     y = __builtin_fma(0.5 * y, e, y);
   }
