@@ -610,7 +610,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (mode == SRH_MODE_BINNED) {
     hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + 255) / 256)), dim3(256), 0, st, F);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
-    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * 16 + 255) / 256)), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + 255) / 256)), dim3(256), 0, st, F);
   }
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   if (mode == SRH_MODE_BINNED) {

@@ -135,10 +135,15 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev F) {
   if (tid == 1023) F.tile_off[F.nbins] = part[1023];
 }
 
-// ---- fill: 16 lanes per primitive, one (primitive, tile) pair per lane and step ----------------------------
+#ifndef SRH_FILL_LANES
+#define SRH_FILL_LANES 16
+#endif
+constexpr int kFillLanes = SRH_FILL_LANES;
+
+// ---- fill: kFillLanes lanes per primitive, one (primitive, tile) pair per lane and step ---------------------
 __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int gidx = t >> 4, sub = t & 15;
+  const int gidx = t / kFillLanes, sub = t % kFillLanes;
   if (gidx >= F.total) return;
   const uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
   const int tx0 = tr[0], ty0 = tr[1], tx1 = tr[2], ty1 = tr[3];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
   uint32_t* cursor = F.counters + kCounterPad + F.nbins;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const uint64_t mask = F.tilemask[gidx];
-  for (int k = sub; k < n; k += 16) {
+  for (int k = sub; k < n; k += kFillLanes) {
     if (!((mask >> k) & 1ull)) continue;
     const int bin = bin0 + (ty0 + k / nx) * F.tiles_x + (tx0 + k % nx);
     const uint32_t slot = atomicAdd(&cursor[bin], 1u);
