@@ -444,6 +444,17 @@ int camera_to_frame(const SrhCamera* cam, FrameDev* F, bool orthonormal = false)
   F->far_clip = cam->far_clip;
   F->W = W;
   F->H = H;
+  // pixel_ray's shared-reciprocal division is the IEEE division bit for bit as long as no operand needs rescaling:
+  // true for ray components that are 0 or at least ~2^-150 in magnitude and lengths within 2^+-150, which camera
+  // parameters of ordinary size guarantee (a cancelled component is 0 or >= 2^-53 of its terms)
+  auto ordinary = [](double v) { const double a = std::fabs(v); return a == 0.0 || (a >= 1e-15 && a <= 1e15); };
+  bool ok = ordinary(F->half_w) && F->half_w != 0.0 && ordinary(F->half_h) && F->half_h != 0.0 &&
+            ordinary(F->focal) && F->focal != 0.0;
+  for (int i = 0; i < 3; ++i) ok = ok && ordinary(F->bx[i]) && ordinary(F->by[i]) && ordinary(F->bz[i]);
+#ifdef SRH_ABL_NODIVSHARE
+  ok = false;
+#endif
+  F->div_shared = ok ? 1 : 0;
   return SRH_OK;
 }
 

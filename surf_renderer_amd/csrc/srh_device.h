@@ -43,7 +43,8 @@ struct FrameDev {
   int32_t nseg, total, nlights, ncolors, nmat, tonemap;
   int64_t img_stride, depth_stride, near_stride;   // elements per output row
   // SRH_SHADING_TORCH extras (torch/renderer.py:82-125)
-  int32_t shading, double_sided, use_quartic, pad2;
+  int32_t shading, double_sided, use_quartic;
+  int32_t div_shared;                // pixel_ray may share one reciprocal between its three divisions (see there)
   const float* latt;                 // (L,3) attenuation or NULL
   const float* coeffs;               // (K,3) material coefficients or NULL
   const float* ambient;              // (3) or NULL
@@ -92,8 +93,27 @@ __device__ __forceinline__ double pixel_ray(const FrameDev& F, int c, int r, dou
 #pragma unroll
   for (int i = 0; i < 3; ++i) v[i] = (F.bx[i] * X + F.by[i] * Y) + F.bz[i] * Z;
   const double len = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  if (F.div_shared) {
+    // The three IEEE divisions by |D| as hipcc expands each of them (v_rcp_f64, two Newton steps, quotient, residual
+    // correction), with the reciprocal refined ONCE: for operands that need no v_div_scale rescaling -- which the
+    // host checks on the camera's magnitudes (camera_to_frame) -- every step is the same arithmetic, so the results
+    // are bit-identical to v[i] / len (tools/ubench_div.hip: 0 mismatches in 2.5e9 divisions on the MI355X, over
+    // 400 binary orders of magnitude).  Saves two of the three quarter-rate reciprocals and 17 instructions per ray.
+    const double r = __builtin_amdgcn_rcp(len);
+    const double e0 = __builtin_fma(-len, r, 1.0);
+    const double r1 = __builtin_fma(r, e0, r);
+    const double e1 = __builtin_fma(-len, r1, 1.0);
+    const double r2 = __builtin_fma(r1, e1, r1);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) d[i] = v[i] / len;
+    for (int i = 0; i < 3; ++i) {
+      const double q = v[i] * r2;
+      const double rem = __builtin_fma(-len, q, v[i]);
+      d[i] = __builtin_fma(rem, r2, q);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = v[i] / len;
+  }
   return len;
 }
 
