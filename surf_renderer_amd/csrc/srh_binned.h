@@ -225,7 +225,7 @@ __device__ __forceinline__ uint32_t key_ordinal(int32_t key) { return ((uint32_t
 
 // fp32 LOWER bound of the ray distance a key stands for (rcp is good to 1 ulp; the factor covers it)
 __device__ __forceinline__ float inv_to_bound(float inv_upper) { return __builtin_amdgcn_rcpf(inv_upper) * 0.9999995f; }
-__device__ __forceinline__ float key_bound(int32_t key) { return inv_to_bound(__uint_as_float((uint32_t)key | kOrdMask)); }
+__device__ __forceinline__ float key_inv(int32_t key) { return __uint_as_float((uint32_t)key | kOrdMask); }   // >= 1 / t
 
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
 __device__ __forceinline__ float float_above(double t) { return (float)t * 1.0000005f; }
@@ -386,9 +386,7 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
-#ifndef SRH_KEYS3
     Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
-#endif
     Q.k3[j] = imed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = imed3(Q.k1[j], key, Q.k2[j]);
     Q.k1[j] = max(Q.k1[j], key);
@@ -860,14 +858,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
         const int32_t keys[3] = {p.k1, p.k2, p.k3};
         bool saturated = false;
+        // a key still "reaches" the confirmed depth iff its inverse-depth bound is >= reach = (1 - 1e-6) / bound
+        // (one reciprocal per confirmation instead of one per key; 0 while nothing is confirmed)
+        float reach = 0.0f;
 #pragma unroll
-#ifdef SRH_KEYS3
-        for (int q = 0; q < 2; ++q) {
-#else
         for (int q = 0; q < 3; ++q) {
-#endif
           const int32_t key = keys[q];
-          if (key != kNoKey && !saturated && key_bound(key) <= bound) {
+          if (key != kNoKey && !saturated && key_inv(key) >= reach) {
             if (key_saturated(key)) {
               saturated = true;
             } else {
@@ -877,15 +874,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
               if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
               else confirm_global<TCH>(F, g, d, best, besti);
               bound = float_above(best);
+              reach = __builtin_amdgcn_rcpf(bound) * 0.999999f;     // bound = inf (a miss) gives 0 again
             }
           }
         }
         // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
-#ifdef SRH_KEYS3
-        slow = saturated || (p.k3 != kNoKey && key_bound(p.k3) <= bound);
-#else
-        slow = saturated || (p.k4 != kNoKey && key_bound(p.k4) <= bound);
-#endif
+        slow = saturated || (p.k4 != kNoKey && key_inv(p.k4) >= reach);
         if (slow) { g1 = g2 = -1; }           // the slow path re-confirms; cheaper than excluding three indices
       }
 #endif
