@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 2
+#define SRH_ABI_VERSION 3
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -183,6 +183,18 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                    const float* grad_image, const float* grad_depth,
                    const int32_t* nearest, const float* depth,
                    const SrhGrads* grads, void* stream);
+
+/* Many views of one scene in one call: the batch axis of the reference's real callers, which render one view per
+ * render() call in a Python loop (diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  `cameras` is an
+ * array of n_views cameras with one viewport size; `params` is shared (whole frames, binned mode, dense outputs);
+ * images (n_views,H,W,3), depths (n_views,H,W), nearests (n_views,H,W; may be NULL) are stacked.  Every kernel of the
+ * frame pipeline is launched once for the whole batch (the view is a grid dimension), so small views cost neither
+ * six launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
+ * srh_workspace_bytes_views(...) bytes.  Not thread-safe (one pinned staging buffer per process). */
+size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views);
+int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
+                     const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                     float* images, float* depths, int32_t* nearests, void* stream);
 
 /* measurement helpers: timing-enabled HIP events usable as SrhParams.ev_start / ev_stop.
  * srh_event_elapsed_ms waits for `stop` to complete (the only call here that blocks the host). */

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -65,7 +65,7 @@ class SrhGrads(C.Structure):
 
 
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
-           "srh_render_bwd",
+           "srh_render_bwd", "srh_workspace_bytes_views", "srh_render_views",
            "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
@@ -112,6 +112,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_render_bwd.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                    C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrhGrads), C.c_void_p]
+    lib.srh_workspace_bytes_views.restype = C.c_size_t
+    lib.srh_workspace_bytes_views.argtypes = [C.POINTER(SrhObjects), C.c_int32, C.c_int32, C.c_int32]
+    lib.srh_render_views.restype = C.c_int
+    lib.srh_render_views.argtypes = [C.c_int32, C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
+                                     C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.srh_event_create.restype = C.c_int
     lib.srh_event_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.srh_event_destroy.restype = C.c_int

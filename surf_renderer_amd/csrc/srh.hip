@@ -83,7 +83,7 @@ __device__ inline bool primitive_misses_slab(const FrameDev& F, const SegDev& S,
   return ball_misses_slab(F, x, rho);
 }
 
-__global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
+__device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec64, float* rec32) {
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
@@ -116,6 +116,13 @@ __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, 
     default: plane_reject_record(R, B, F.W, F.H, Q); break;
   }
   if (F.tilerange) bin_primitive(F, s, S.type, Q, S.first + i);
+}
+
+__global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
+
+__global__ __launch_bounds__(256) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
+  const FrameDev& F = Fs[blockIdx.y];
+  prep_body(F, s, const_cast<double*>(F.seg[s].rec64), const_cast<float*>(F.seg[s].rec32));
 }
 
 __device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R) {
@@ -571,6 +578,37 @@ int srh_generate_rays(const SrhCamera* camera, int32_t row0, int32_t row1, float
   return e == hipSuccess ? SRH_OK : hip_fail(e, "k_rays launch");
 }
 
+// Tile-binning fields of a frame whose primitive records live in `workspace` (layout L).
+static void setup_binning(FrameDev& F, const WsLayout& L, void* workspace) {
+    F.tiles_x = L.tiles_x;
+  F.tiles_y = (F.row1 - F.row0 + kTile - 1) / kTile;
+  F.ntiles = F.tiles_x * F.tiles_y;
+  F.ntiles_pad = (F.ntiles + 3) / 4 * 4;
+  F.nbins = F.nseg * F.ntiles_pad;
+  char* ws = (char*)workspace;
+  F.tilerange = (uint16_t*)(ws + L.tilerange);
+  F.tilemask = (uint64_t*)(ws + L.tilemask);
+  F.counters = (uint32_t*)(ws + L.counters);
+  F.tile_off = (uint32_t*)(ws + L.tile_off);
+  F.large = (uint32_t*)(ws + L.large);
+  F.entries = (uint32_t*)(ws + L.entries);
+  F.slab_cull = 0;
+  if (F.row0 > 0 || F.row1 < F.H) {
+    // rows of [D0 Dc Dr]^-1 via the adjugate (cross products)
+    const PixelBasis B = pixel_basis(F);
+    const double* p0 = B.D0; const double* pc = B.Dc; const double* pr = B.Dr;
+    const double cx[3] = {pc[1] * pr[2] - pc[2] * pr[1], pc[2] * pr[0] - pc[0] * pr[2], pc[0] * pr[1] - pc[1] * pr[0]};
+    const double cg[3] = {p0[1] * pc[2] - p0[2] * pc[1], p0[2] * pc[0] - p0[0] * pc[2], p0[0] * pc[1] - p0[1] * pc[0]};
+    const double det = p0[0] * cx[0] + p0[1] * cx[1] + p0[2] * cx[2];
+    if (std::isfinite(det) && std::fabs(det) > 0.0) {
+      for (int k = 0; k < 3; ++k) { F.slab_ma[k] = cx[k] / det; F.slab_mg[k] = cg[k] / det; }
+      F.slab_na = std::sqrt(F.slab_ma[0] * F.slab_ma[0] + F.slab_ma[1] * F.slab_ma[1] + F.slab_ma[2] * F.slab_ma[2]) * 1.000001;
+      F.slab_ng = std::sqrt(F.slab_mg[0] * F.slab_mg[0] + F.slab_mg[1] * F.slab_mg[1] + F.slab_mg[2] * F.slab_mg[2]) * 1.000001;
+      F.slab_cull = std::isfinite(F.slab_na) && std::isfinite(F.slab_ng) ? 1 : 0;
+    }
+  }
+}
+
 int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
                    const SrhMaterials* materials, const SrhParams* params, void* workspace,
                    size_t workspace_bytes, float* image, float* depth, int32_t* nearest, void* stream) {
@@ -582,33 +620,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   const int mode = params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode;
   hipStream_t st = (hipStream_t)stream;
   if (mode == SRH_MODE_BINNED) {
-    F.tiles_x = L.tiles_x;
-    F.tiles_y = (F.row1 - F.row0 + kTile - 1) / kTile;
-    F.ntiles = F.tiles_x * F.tiles_y;
-    F.ntiles_pad = (F.ntiles + 3) / 4 * 4;
-    F.nbins = F.nseg * F.ntiles_pad;
-    char* ws = (char*)workspace;
-    F.tilerange = (uint16_t*)(ws + L.tilerange);
-    F.tilemask = (uint64_t*)(ws + L.tilemask);
-    F.counters = (uint32_t*)(ws + L.counters);
-    F.tile_off = (uint32_t*)(ws + L.tile_off);
-    F.large = (uint32_t*)(ws + L.large);
-    F.entries = (uint32_t*)(ws + L.entries);
-    F.slab_cull = 0;
-    if (F.row0 > 0 || F.row1 < F.H) {
-      // rows of [D0 Dc Dr]^-1 via the adjugate (cross products)
-      const PixelBasis B = pixel_basis(F);
-      const double* p0 = B.D0; const double* pc = B.Dc; const double* pr = B.Dr;
-      const double cx[3] = {pc[1] * pr[2] - pc[2] * pr[1], pc[2] * pr[0] - pc[0] * pr[2], pc[0] * pr[1] - pc[1] * pr[0]};
-      const double cg[3] = {p0[1] * pc[2] - p0[2] * pc[1], p0[2] * pc[0] - p0[0] * pc[2], p0[0] * pc[1] - p0[1] * pc[0]};
-      const double det = p0[0] * cx[0] + p0[1] * cx[1] + p0[2] * cx[2];
-      if (std::isfinite(det) && std::fabs(det) > 0.0) {
-        for (int k = 0; k < 3; ++k) { F.slab_ma[k] = cx[k] / det; F.slab_mg[k] = cg[k] / det; }
-        F.slab_na = std::sqrt(F.slab_ma[0] * F.slab_ma[0] + F.slab_ma[1] * F.slab_ma[1] + F.slab_ma[2] * F.slab_ma[2]) * 1.000001;
-        F.slab_ng = std::sqrt(F.slab_mg[0] * F.slab_mg[0] + F.slab_mg[1] * F.slab_mg[1] + F.slab_mg[2] * F.slab_mg[2]) * 1.000001;
-        F.slab_cull = std::isfinite(F.slab_na) && std::isfinite(F.slab_ng) ? 1 : 0;
-      }
-    }
+    setup_binning(F, L, workspace);
     hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);
     if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
   }
@@ -649,6 +661,94 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (params->ev_stop) (void)hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "render launch");
+}
+
+// ---- many views of one scene per call ---------------------------------------------------------------------------
+namespace {
+size_t views_header_bytes(int n_views) { return align_up((size_t)n_views * sizeof(FrameDev)); }
+FrameDev* g_stage = nullptr;          // pinned staging for the FrameDev array of the batch being submitted
+size_t g_stage_cap = 0;
+hipEvent_t g_stage_done = nullptr;    // the previous batch's upload from g_stage has finished
+}  // namespace
+
+size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views) {
+  const size_t one = srh_workspace_bytes(objects, width, height);
+  if (!one) return 0;
+  if (n_views < 1 || n_views > 65535) {
+    fail(SRH_E_RANGE, "n_views = %d, expected 1..65535", n_views);
+    return 0;
+  }
+  return views_header_bytes(n_views) + (size_t)n_views * one;
+}
+
+int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
+                     const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                     float* images, float* depths, int32_t* nearests, void* stream) {
+  if (!cameras || !params || !workspace) return fail(SRH_E_NULL, "cameras / params / workspace is NULL");
+  if (!images || !depths) return fail(SRH_E_NULL, "images / depths is NULL");
+  if (n_views < 1 || n_views > 65535) return fail(SRH_E_RANGE, "n_views = %d, expected 1..65535", n_views);
+  if (params->mode != SRH_MODE_AUTO && params->mode != SRH_MODE_BINNED)
+    return fail(SRH_E_TYPE, "srh_render_views renders in the binned mode only");
+  if (params->normal_out || params->pos_out || params->ev_start || params->ev_stop)
+    return fail(SRH_E_TYPE, "srh_render_views: normal / pos outputs and event hooks are per-frame features");
+  const int W = cameras[0].viewport[2] - cameras[0].viewport[0], H = cameras[0].viewport[3] - cameras[0].viewport[1];
+  const size_t one = srh_workspace_bytes(objects, W, H);
+  if (!one) return SRH_E_RANGE;               // srh_workspace_bytes left the message
+  const size_t head = views_header_bytes(n_views);
+  if (workspace_bytes < head + (size_t)n_views * one)
+    return fail(SRH_E_RANGE, "workspace holds %zu bytes, %d views need %zu", workspace_bytes, n_views,
+                head + (size_t)n_views * one);
+  hipStream_t st = (hipStream_t)stream;
+  // pinned staging, reused from batch to batch once the previous upload has left it
+  if (!g_stage_done) {
+    const hipError_t ee = hipEventCreateWithFlags(&g_stage_done, hipEventDisableTiming);
+    if (ee != hipSuccess) { g_stage_done = nullptr; return hip_fail(ee, "hipEventCreate"); }
+  }
+  if (g_stage_cap < (size_t)n_views) {
+    if (g_stage) { (void)hipEventSynchronize(g_stage_done); (void)hipHostFree(g_stage); g_stage = nullptr; g_stage_cap = 0; }
+    const hipError_t em = hipHostMalloc((void**)&g_stage, (size_t)n_views * sizeof(FrameDev), hipHostMallocDefault);
+    if (em != hipSuccess) { g_stage = nullptr; return hip_fail(em, "hipHostMalloc(frames)"); }
+    g_stage_cap = (size_t)n_views;
+  } else {
+    (void)hipEventSynchronize(g_stage_done);
+  }
+  char* ws = (char*)workspace;
+  WsLayout L;
+  for (int v = 0; v < n_views; ++v) {
+    const int w = cameras[v].viewport[2] - cameras[v].viewport[0], h = cameras[v].viewport[3] - cameras[v].viewport[1];
+    if (w != W || h != H) return fail(SRH_E_RANGE, "view %d is %d x %d, view 0 is %d x %d", v, w, h, W, H);
+    FrameDev& F = g_stage[v];
+    int rc = setup_frame(&cameras[v], objects, lights, materials, params, ws + head + (size_t)v * one, one, &F, &L);
+    if (rc) return rc;
+    if (F.row0 != 0 || F.row1 != F.H) return fail(SRH_E_RANGE, "srh_render_views renders whole frames (rows 0..H)");
+    setup_binning(F, L, ws + head + (size_t)v * one);
+  }
+  const FrameDev* Fs = (const FrameDev*)ws;
+  hipError_t e = hipMemcpyAsync(ws, g_stage, (size_t)n_views * sizeof(FrameDev), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(frames)");
+  (void)hipEventRecord(g_stage_done, st);
+  const FrameDev& F0 = g_stage[0];
+  const unsigned V = (unsigned)n_views;
+  const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F0.nbins;
+  hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
+  for (int s = 0; s < F0.nseg; ++s)
+    hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + 255) / 256, V), dim3(256), 0, st, Fs, s);
+  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + 255) / 256), V), dim3(256), 0, st, Fs);
+  hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, Fs);
+  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)F0.total * kFillLanes + 255) / 256), V), dim3(256), 0, st, Fs);
+  const unsigned groups = binned_grid(F0);
+  // all views share the GPU, so the batch as a whole decides the launch shape
+  const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4)
+                         ? params->waves_per_tile == 4 : (size_t)F0.ntiles * V < (size_t)SRH_SPLIT_TILES;
+  if (F0.shading) {
+    if (split) hipLaunchKernelGGL((k_render_binned_views<true, 4>), dim3(groups * 4, V), dim3(256), 0, st, Fs, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups, V), dim3(256), 0, st, Fs, images, depths, nearests);
+  } else {
+    if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, Fs, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups, V), dim3(256), 0, st, Fs, images, depths, nearests);
+  }
+  e = hipGetLastError();
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "views launch");
 }
 
 int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,

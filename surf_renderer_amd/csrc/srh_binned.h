@@ -69,7 +69,7 @@ constexpr int kCountLanes = SRH_COUNT_LANES;
 // the eye; bit k of the primitive's tile mask = k-th tile of the box, row-major.  k_prep leaves this to a kernel of
 // its own because a thread per primitive walking up to 64 tiles in fp64 is a long serial chain on a launch that
 // has only a wave or two per SIMD.
-__global__ __launch_bounds__(256) void k_bin_count(FrameDev F) {
+__device__ __forceinline__ void bin_count_body(const FrameDev& F) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int gidx = t / kCountLanes, sub = t % kCountLanes;
   if (gidx >= F.total) return;                                  // whole lane groups leave together
@@ -102,8 +102,10 @@ __global__ __launch_bounds__(256) void k_bin_count(FrameDev F) {
   if (sub == 0) F.tilemask[gidx] = ((uint64_t)hi << 32) | lo;
 }
 
+__global__ __launch_bounds__(256) void k_bin_count(FrameDev F) { bin_count_body(F); }
+
 // ---- exclusive scan of the bin counts: one 1024-thread workgroup, 16-byte loads ---------------------------
-__global__ __launch_bounds__(1024) void k_bin_scan(FrameDev F) {
+__device__ __forceinline__ void bin_scan_body(const FrameDev& F) {
   __shared__ uint32_t part[1024];
   const int tid = threadIdx.x;
   const int n4 = F.nbins / 4;                              // nbins is a multiple of 4
@@ -135,13 +137,15 @@ __global__ __launch_bounds__(1024) void k_bin_scan(FrameDev F) {
   if (tid == 1023) F.tile_off[F.nbins] = part[1023];
 }
 
+__global__ __launch_bounds__(1024) void k_bin_scan(FrameDev F) { bin_scan_body(F); }
+
 #ifndef SRH_FILL_LANES
 #define SRH_FILL_LANES 16
 #endif
 constexpr int kFillLanes = SRH_FILL_LANES;
 
 // ---- fill: kFillLanes lanes per primitive, one (primitive, tile) pair per lane and step ---------------------
-__global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
+__device__ __forceinline__ void bin_fill_body(const FrameDev& F) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int gidx = t / kFillLanes, sub = t % kFillLanes;
   if (gidx >= F.total) return;
@@ -159,6 +163,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) {
     F.entries[F.tile_off[bin] + slot] = (uint32_t)gidx;
   }
 }
+
+__global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) { bin_fill_body(F); }
 
 // ---- render: one wave per 16x16-pixel tile, four pixels (one row quad) per lane ---------------------------------
 //
@@ -694,8 +700,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // latency per tile and four times the waves: for frames (or row slabs of a multi-GPU job) with too few tiles to
 // fill 1024 SIMDs several times over.
 template <bool TCH, int WPT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(FrameDev F, float* __restrict__ image,
-                                                        float* __restrict__ depth, int32_t* __restrict__ nearest) {
+__device__ __forceinline__ void render_binned_body(const FrameDev& F, float* __restrict__ image,
+                                                   float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
   __shared__ int32_t front[4][4][64];         // global index of each pixel's front candidate (-1: none / saturated)
   __shared__ uint8_t queue[4][256];           // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
@@ -926,6 +932,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
       }
     }
   }
+}
+
+template <bool TCH, int WPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(
+    FrameDev F, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  render_binned_body<TCH, WPT>(F, image, depth, nearest);
+}
+
+// ---- many views per launch (srh_render_views): blockIdx.y selects the view, whose FrameDev lives in device memory;
+// the views' outputs are stacked (V, rows, W, .) -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_views_zero(const FrameDev* __restrict__ Fs) {
+  const FrameDev& F = Fs[blockIdx.y];
+  const size_t n = (size_t)kCounterPad + 2 * (size_t)F.nbins;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) F.counters[i] = 0u;
+}
+__global__ __launch_bounds__(256) void k_bin_count_views(const FrameDev* __restrict__ Fs) { bin_count_body(Fs[blockIdx.y]); }
+__global__ __launch_bounds__(1024) void k_bin_scan_views(const FrameDev* __restrict__ Fs) { bin_scan_body(Fs[blockIdx.y]); }
+__global__ __launch_bounds__(256) void k_bin_fill_views(const FrameDev* __restrict__ Fs) { bin_fill_body(Fs[blockIdx.y]); }
+
+template <bool TCH, int WPT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned_views(
+    const FrameDev* __restrict__ Fs, float* __restrict__ image, float* __restrict__ depth,
+    int32_t* __restrict__ nearest) {
+  const FrameDev& F = Fs[blockIdx.y];
+  const size_t rows = (size_t)(F.row1 - F.row0), v = blockIdx.y;
+  render_binned_body<TCH, WPT>(F, image + v * rows * F.img_stride, depth + v * rows * F.depth_stride,
+                               nearest ? nearest + v * rows * F.near_stride : nullptr);
 }
 
 }  // namespace srh

@@ -409,13 +409,15 @@ class _RenderFunction(torch.autograd.Function):
 
 
 def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], device="cuda", mode: str = "auto",
-                 streams: int = 4, want_nearest: bool = True, **shading_kw) -> Dict[str, torch.Tensor]:
+                 streams: int = 4, want_nearest: bool = True, batch: int = 256, **shading_kw) -> Dict[str, torch.Tensor]:
     """Many cameras, one scene: the batch axis of the reference's real callers (one ``render()`` per view in a
-    Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once; views
-    are issued round-robin over ``streams`` HIP streams, each with its own scratch, so the small latency-bound
-    kernels of one view overlap the others.  All cameras must share one viewport size.  Returns stacked tensors
-    ``image`` (B,H,W,3), ``depth`` (B,H,W) and ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` /
-    ``use_quartic`` as in ``render``.  Forward only."""
+    Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once.  In the
+    default binned mode the views go to the library ``batch`` at a time (``srh_render_views``): every kernel of the
+    frame pipeline is launched once per batch with the view as a grid dimension, so small views neither pay six
+    launches each nor leave the GPU idle.  Other modes, or ``batch=0``, issue one call per view round-robin over
+    ``streams`` HIP streams.  All
+    cameras must share one viewport size.  Returns stacked tensors ``image`` (B,H,W,3), ``depth`` (B,H,W) and
+    ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` / ``use_quartic`` as in ``render``.  Forward only."""
     device = torch.device(device)
     buf = flatten_scene(scene, device)
     cams = [camera_struct(c) for c in cameras]
@@ -428,6 +430,32 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     image = torch.empty((n, height, width, 3), dtype=torch.float32, device=device)
     depth = torch.empty((n, height, width), dtype=torch.float32, device=device)
     nearest = torch.empty((n, height, width), dtype=torch.int32, device=device) if want_nearest else None
+    out = {"image": image, "depth": depth}
+    if want_nearest:
+        out["nearest"] = nearest
+    if mode in ("auto", "binned") and int(batch) > 0:
+        lib = _lib.load()
+        shading = shading_kw.get("shading", "numpy")
+        params = _lib.SrhParams(row0=0, row1=height, mode=_lib.MODES[mode],
+                                tonemap_gamma=0 if buf.gamma is None else 1,
+                                gamma=1.0 if buf.gamma is None else buf.gamma,
+                                shading=_lib.SHADING[shading], double_sided=int(bool(shading_kw.get("double_sided", False))),
+                                use_quartic=int(bool(shading_kw.get("use_quartic", False))),
+                                waves_per_tile=int(shading_kw.get("waves_per_tile", 0)))
+        step = max(1, min(int(batch), n))
+        nbytes = lib.srh_workspace_bytes_views(C.byref(buf.objects), width, height, step)
+        if nbytes == 0:
+            raise _lib.SrhError(-2, lib.srh_last_error().decode())
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            for i in range(0, n, step):
+                m = min(step, n - i)
+                arr = (_lib.SrhCamera * m)(*cams[i:i + m])
+                _lib.check(lib.srh_render_views(m, arr, C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                                C.byref(params), workspace.data_ptr(), workspace.numel(),
+                                                image[i].data_ptr(), depth[i].data_ptr(),
+                                                nearest[i].data_ptr() if want_nearest else None, _stream_ptr(device)))
+        return out
     n_streams = max(1, min(int(streams), n))
     pool = [torch.cuda.Stream(device) for _ in range(n_streams)]
     scratch = [buf.new_workspace(width, height) for _ in range(n_streams)]
@@ -444,9 +472,6 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     for t in (image, depth, nearest, *scratch, *buf.tensors.values()):
         if t is not None:
             t.record_stream(current)
-    out = {"image": image, "depth": depth}
-    if want_nearest:
-        out["nearest"] = nearest
     return out
 
 

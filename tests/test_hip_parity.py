@@ -223,15 +223,31 @@ def test_render_views_equals_per_view_render():
         eye = 10.0 * eye / np.linalg.norm(eye)
         cam["eye"] = [float(eye[0]), float(eye[1]), float(eye[2]), 1.0]
         cams.append(cam)
-    batch = render_views(scene, cams, device="cuda:0", streams=3)
-    torch.cuda.synchronize()
-    assert batch["image"].shape == (7, 80, 96, 3)
-    for i, cam in enumerate(cams):
-        single = render({**scene, "camera": cam}, device="cuda:0")
-        np.testing.assert_array_equal(batch["image"][i].cpu().numpy(), single["image"].cpu().numpy())
-        np.testing.assert_array_equal(batch["depth"][i].cpu().numpy(), single["depth"].cpu().numpy())
-        np.testing.assert_array_equal(batch["nearest"][i].cpu().numpy(), single["nearest"].cpu().numpy())
+    singles = [render({**scene, "camera": cam}, device="cuda:0") for cam in cams]
+    # one library call per batch of views (batches of 3 -> 3 + 3 + 1, and all 7 at once), and the stream-pool path
+    for kw in ({"batch": 3}, {"batch": 256}, {"batch": 0, "streams": 3}, {"mode": "fast", "streams": 2}):
+        batch = render_views(scene, cams, device="cuda:0", **kw)
+        torch.cuda.synchronize()
+        assert batch["image"].shape == (7, 80, 96, 3)
+        for i, single in enumerate(singles):
+            for k in ("image", "depth", "nearest"):
+                np.testing.assert_array_equal(batch[k][i].cpu().numpy(), single[k].cpu().numpy(), err_msg=f"{kw} view {i} {k}")
     assert np.isfinite(batch["depth"].cpu().numpy()).mean() > 0.05
+    # torch shading, a mixed scene with frame-wide primitives (planes), larger views
+    scene2 = synthetic.demo_scene(200, 144, with_planes=True)
+    scene2["lights"]["attenuation"] = np.array([[1, 0, 0]] * 4, dtype=np.float32)
+    scene2["lights"]["ambient"] = np.array([0.02, 0.02, 0.02], dtype=np.float32)
+    scene2["materials"]["coeffs"] = np.array([[0.8, 0.2, 6.0]] * len(scene2["materials"]["albedo"]), dtype=np.float32)
+    cams2 = []
+    for k in range(5):
+        cam = dict(scene2["camera"])
+        cam["eye"] = [float(3.0 * np.cos(k)), 1.0 + 0.3 * k, float(10.0 + np.sin(k)), 1.0]
+        cams2.append(cam)
+    batch = render_views(scene2, cams2, device="cuda:0", shading="torch", double_sided=True)
+    for i, cam in enumerate(cams2):
+        single = render({**scene2, "camera": cam}, device="cuda:0", shading="torch", double_sided=True)
+        for k in ("image", "depth", "nearest"):
+            np.testing.assert_array_equal(batch[k][i].cpu().numpy(), single[k].cpu().numpy(), err_msg=f"torch view {i} {k}")
 
 
 @pytest.mark.gpu

@@ -74,10 +74,15 @@ def batched_views():
         eye = rng.normal(size=3)
         eye = 10.0 * eye / np.linalg.norm(eye)
         cams.append(dict(scene["camera"], eye=[float(eye[0]), float(eye[1]), float(eye[2]), 1.0]))
-    for streams in (1, 4, 8):
-        dt = timed(lambda: renderer.render_views(scene, cams, device="cuda:0", streams=streams), steps=10, warmup=2)
-        print(json.dumps({"config": f"f4: 64 views x bunny.splat 128x128, {streams} stream(s), scene upload included",
-                          "ms_per_batch": 1e3 * dt, "views_per_s": 64 / dt}), flush=True)
+    for streams in (1, 8):
+        dt = timed(lambda: renderer.render_views(scene, cams, device="cuda:0", streams=streams, batch=0), steps=10, warmup=2)
+        print(json.dumps({"config": f"f4: 64 views x bunny.splat 128x128, one call per view on {streams} stream(s), "
+                                    "scene upload included", "ms_per_batch": 1e3 * dt, "views_per_s": 64 / dt}), flush=True)
+    for n in (64, 1024):
+        many = (cams * ((n + 63) // 64))[:n]
+        dt = timed(lambda: renderer.render_views(scene, many, device="cuda:0"), steps=10, warmup=2)
+        print(json.dumps({"config": f"f4: {n} views x bunny.splat 128x128, srh_render_views (view = grid dimension), "
+                                    "scene upload included", "ms_per_batch": 1e3 * dt, "views_per_s": n / dt}), flush=True)
 
 
 if __name__ == "__main__":
