@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--as-rank", default=None, metavar="R/P",
                     help="single-process rehearsal: render only the row slab rank R of a P-rank job would own (no "
                          "collection), to size the per-rank cost of the multi-GPU path on one GPU")
+    ap.add_argument("--parallelism", default="rows", choices=["rows", "frames"],
+                    help="rows (the metric's definition): every frame is row-tiled over the ranks and collected.  "
+                         "frames: every rank renders whole frames of its own, nothing is collected -- the axis the "
+                         "reference's callers actually have (SURVEY 8f row f4); reported as weak scaling")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -123,7 +127,8 @@ def main():
     scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
     buf = renderer.flatten_scene(scene, device)
     cam = renderer.camera_struct(scene["camera"])
-    r0, r1 = row_slab(H, rank, world)
+    frames_par = args.parallelism == "frames" and world > 1
+    r0, r1 = (0, H) if frames_par else row_slab(H, rank, world)
     if args.as_rank:
         er, ep = (int(t) for t in args.as_rank.split("/"))
         r0, r1 = row_slab(H, er, ep)
@@ -141,7 +146,7 @@ def main():
     streams = [torch.cuda.Stream(device) for _ in range(n_str)]
     scratch = [buf.new_workspace(W, H) for _ in range(n_str)]
     equal_slabs = H % world == 0
-    batched = use_dist and equal_slabs and args.gather == "alltoall"
+    batched = use_dist and equal_slabs and args.gather == "alltoall" and not frames_par
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
@@ -228,7 +233,7 @@ def main():
         n_buf = n_str
         frames, slabs = [], []
         for _ in range(n_buf):
-            if rank == 0:
+            if rank == 0 or frames_par:
                 frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
                 slab = frame[r0:r1] if not args.as_rank else torch.empty((h, 4 * W), dtype=torch.float32, device=device)
             else:
@@ -247,7 +252,7 @@ def main():
                 pending[b] = None
             image, depth = views(slabs[b])
             enqueue((b,), streams[b], image, depth, scratch[b], ev)
-            if use_dist:
+            if use_dist and not frames_par:
                 with torch.cuda.stream(streams[b]):
                     pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
 
@@ -304,7 +309,7 @@ def main():
             e.close()
 
     if rank == 0:
-        fps = args.steps / elapsed
+        fps = args.steps / elapsed * (world if frames_par else 1)      # every rank delivered `steps` whole frames
         tests = float(M) * W * H
         # algorithmic HBM bytes of one render launch on this rank: primitives read once in the
         # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
@@ -317,7 +322,8 @@ def main():
             "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "gtests_per_s": fps * tests / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if frames_par else "strong",
             "vs_baseline": None,
             "dtype": "f64" if args.mode == "exact" else "f32 reject + f64 confirm",
             "data": "synthetic",
@@ -327,8 +333,9 @@ def main():
                        "frames_in_flight": n_str,
                        "launch": f"hipGraph replay ({graph_state['captured']} graphs)" if graph_state["on"] and graphs
                                  else "eager",
-                       "parallelism": f"rows/{world}" if not args.as_rank else f"rehearsal of rank {args.as_rank}",
-                       "collection": "none" if not use_dist else
+                       "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
+                                      else f"rehearsal of rank {args.as_rank}",
+                       "collection": "none" if (not use_dist or frames_par) else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
