@@ -37,7 +37,7 @@ def f32(a):
 
 
 def to_torch(sc):
-    t = {"camera": dict(sc["camera"], proj_type="perspective")}
+    t = {"camera": dict(sc["camera"], proj_type=sc["camera"].get("proj_type", "perspective"))}
     for k in ("eye", "at", "up"):
         t["camera"][k] = torch.tensor(np.asarray(sc["camera"][k], dtype=np.float32))
     t["lights"] = {"pos": torch.tensor(np.asarray(sc["lights"]["pos"], dtype=np.float32)),
@@ -99,6 +99,21 @@ def main():
     t3["materials"]["coeffs"] = f32([[1, 0, 0]])
     emit("t3_disk_cloud_64x64_ds", t3, double_sided=True)
     emit("t3_disk_cloud_64x64", t3)
+
+    # t4: orthographic projection (torch/utils.py:461-468; the reference's ortho branch only works while the image
+    # fits one 4096-pixel tile), the mixed scene and a disc cloud
+    t4 = synthetic.demo_scene(64, 48, with_planes=True)
+    t4["camera"].update(proj_type="ortho", near=0.5, fovy=float(np.deg2rad(100.0)), focal_length=4.0)
+    t4["lights"]["attenuation"] = f32([[1, 0, 0], [0.2, 0.05, 0], [1, 0, 0.001], [0.7, 0.02, 0.0005]])
+    t4["lights"]["ambient"] = f32([0.02, 0.015, 0.01])
+    t4["materials"]["coeffs"] = f32([[1, 0, 0], [0.8, 0.2, 4], [0.6, 0.4, 16], [0.9, 0.1, 2], [0.5, 0.5, 8], [0.7, 0.3, 32]])
+    emit("t4_mixed_ortho_64x48", t4)
+    t5 = synthetic.disk_cloud_scene(1500, 64, 64, radius=0.07, seed=22)
+    t5["camera"].update(proj_type="orthographic", fovy=float(np.deg2rad(60.0)), focal_length=2.0)
+    t5["lights"]["attenuation"] = f32([[1, 0, 0]] * 4)
+    t5["lights"]["ambient"] = f32([0.01, 0.01, 0.01])
+    t5["materials"]["coeffs"] = f32([[0.9, 0.1, 3.0]])
+    emit("t5_disk_cloud_ortho_64x64_ds", t5, double_sided=True)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ def pack_scene(scene: Dict[str, Any]) -> Dict[str, np.ndarray]:
     cam = scene["camera"]
     meta = {"objects_order": list(scene["objects"].keys()),
             "camera_list_typed": [k for k in _CAM_VECS if isinstance(cam[k], (list, tuple))],
-            "has_tonemap": "tonemap" in scene}
+            "has_tonemap": "tonemap" in scene, "proj_type": str(cam.get("proj_type", "perspective"))}
     for k in _CAM_VECS:
         flat[f"scene/camera/{k}"] = np.asarray(cam[k], dtype=np.float64)
     flat["scene/camera/viewport"] = np.asarray(cam["viewport"], dtype=np.int64)
@@ -61,6 +61,8 @@ def unpack_scene(npz) -> Dict[str, Any]:
     cam["viewport"] = [int(t) for t in npz["scene/camera/viewport"]]
     for k in ("fovy", "focal_length", "near", "far"):
         cam[k] = float(npz[f"scene/camera/{k}"])
+    if meta.get("proj_type", "perspective") != "perspective":
+        cam["proj_type"] = meta["proj_type"]
     scene: Dict[str, Any] = {
         "camera": cam,
         "lights": {"pos": npz["scene/lights/pos"].astype(np.float64),

@@ -29,6 +29,122 @@ def unit3(u):
     return u / np.where(np.abs(den) > 0, den, 1.0)
 
 
+def is_ortho(camera):
+    return str(camera.get('proj_type', 'perspective')) in ('ortho', 'orthographic')
+
+
+def generate_rays_ortho(camera):
+    """torch/utils.py:439-468 (orthographic branch): every ray has the direction normalize(at - eye) and its own
+    origin eye + x*X + y*Y on the image plane through the eye (lookat_inv, :385-400)."""
+    vp = camera['viewport']
+    W, H = vp[2] - vp[0], vp[3] - vp[1]
+    h = np.tan(camera['fovy'] / 2) * 2 * camera['focal_length']
+    w = h * (float(W) / float(H))
+    x, y = np.meshgrid(np.linspace(-1, 1, W), np.linspace(1, -1, H))
+    x = x.ravel() * (w / 2)
+    y = y.ravel() * (h / 2)
+    eye = np.asarray(camera['eye'], dtype=np.float64)[:3]
+    at = np.asarray(camera['at'], dtype=np.float64)[:3]
+    up = np.asarray(camera['up'], dtype=np.float64)[:3]
+    z = unit3(eye - at)
+    xb = unit3(np.cross(unit3(up), z))
+    yb = np.cross(z, xb)
+    orig = eye[None, :] + x[:, None] * xb[None, :] + y[:, None] * yb[None, :]      # (N,3)
+    return eye, orig, unit3(at - eye), H, W
+
+
+def _render_ortho(scene, double_sided, use_quartic):
+    """The orthographic frame: same pipeline as `render` with per-ray origins and one direction."""
+    cam = scene['camera']
+    eye, orig, dvec, H, W = generate_rays_ortho(cam)
+    npix = H * W
+    near, far = cam['near'], cam['far']
+    objs = {k: {f: np.asarray(v, dtype=np.float64) if f != 'material_idx' else np.asarray(v) for f, v in g.items()}
+            for k, g in scene['objects'].items()}
+    segs, total = np_oracle._segments(objs)
+    material_idx = np.concatenate([g['material_idx'] for _, _, _, g in segs], axis=0).astype(np.int64)
+    t_all = np.empty((total, npix))
+    with np.errstate(all='ignore'):
+        for kind, start, count, g in segs:
+            if kind == 'sphere':
+                oc = orig[None, :, :] - g['pos'][:, None, :3]                      # (M,N,3)
+                b = 2 * np.sum(oc * dvec[None, None, :], axis=-1)
+                c = np.sum(oc ** 2, axis=-1) - (g['radius'] ** 2)[:, None]
+                disc = b ** 2 - 4 * c
+                ok = disc >= 0
+                root = np.sqrt(np.where(ok, disc, 0.0))
+                t1 = (-b - root) / 2
+                t2 = (-b + root) / 2
+                t = np.minimum(np.where(ok & (t1 >= 0), t1, np.inf), np.where(ok & (t2 >= 0), t2, np.inf))
+            else:
+                nrm = unit3(g['normal'][:, :3])
+                q = g['face'][:, 0, :3] if kind == 'triangle' else g['pos'][:, :3]
+                den = nrm @ dvec                                                  # (M,)
+                t = (np.sum(q * nrm, axis=1)[:, None] - nrm @ orig.T) / den[:, None]
+                p = orig[None, :, :] + t[:, :, None] * dvec[None, None, :]
+                if kind == 'disk':
+                    inside = np.sum((p - g['pos'][:, None, :3]) ** 2, axis=-1) <= (g['radius'] ** 2)[:, None]
+                    t = np.where(inside, t, np.inf)
+                elif kind == 'triangle':
+                    inside = np.ones_like(t, dtype=bool)
+                    for i in range(3):
+                        edge = (g['face'][:, (i + 1) % 3, :3] - g['face'][:, i, :3])[:, None, :]
+                        rel = p - g['face'][:, i, :3][:, None, :]
+                        inside &= np.sum(np.cross(edge, rel) * nrm[:, None, :], axis=-1) >= 0
+                    t = np.where(inside, t, np.inf)
+            t_all[start:start + count] = t
+        valid = (near <= t_all) & (t_all <= far)
+        t_all[~valid] = np.inf
+        win = np.argmin(t_all, axis=0)
+        z = t_all[win, np.arange(npix)]
+        hit = np.isfinite(z)
+        p = orig + np.where(hit, z, 0.0)[:, None] * dvec[None, :]
+        fn = np.zeros((npix, 3))
+        for kind, start, count, g in segs:
+            sel = hit & (win >= start) & (win < start + count)
+            if np.any(sel):
+                loc = win[sel] - start
+                fn[sel] = unit3(p[sel] - g['pos'][loc, :3]) if kind == 'sphere' else unit3(g['normal'][:, :3])[loc]
+        im = _fragment_shader(scene, eye, p, fn, material_idx[win], double_sided, use_quartic)
+        im = np.maximum(np.where(hit[:, None], im, 0.0), 0.0)
+        if 'tonemap' in scene:
+            im = im ** float(np.ravel(scene['tonemap']['gamma'])[0])
+    return {'image': im.reshape(H, W, 3), 'depth': np.where(hit, z, far + 1.0).reshape(H, W),
+            'nearest': np.where(hit, win, 0).reshape(H, W), 'normal': np.where(hit[:, None], fn, 0.0).reshape(H, W, 3),
+            'pos': np.where(hit[:, None], p, 0.0).reshape(H, W, 3)}
+
+
+def _fragment_shader(scene, eye, p, fn, mat, double_sided, use_quartic):
+    """torch/renderer.py:82-125 for fragments p (n,3) with normals fn (n,3) and material indices mat (n,)."""
+    lpos = np.asarray(scene['lights']['pos'], dtype=np.float64)[:, :3]
+    lcol = np.asarray(scene['colors'], dtype=np.float64)[np.asarray(scene['lights']['color_idx'])]
+    att = np.asarray(scene['lights']['attenuation'], dtype=np.float64)
+    ambient = np.asarray(scene['lights']['ambient'], dtype=np.float64)
+    alb = np.asarray(scene['materials']['albedo'], dtype=np.float64)[mat]
+    cf = np.asarray(scene['materials']['coeffs'], dtype=np.float64)[mat]
+    ldir = lpos[:, None, :] - p[None, :, :]
+    lnorm = np.sqrt(np.sum(ldir ** 2, axis=-1))[..., None]
+    ldir = ldir / np.where(np.abs(lnorm) > 0, lnorm, 1.0)
+    powv = 4 if use_quartic else 2
+    den = att[:, 0][:, None, None] + lnorm * att[:, 1][:, None, None] + (lnorm ** powv) * att[:, 2][:, None, None]
+    afac = 1.0 / np.where(np.abs(den) > 0, den, 1.0)
+    ndotl = np.sum(fn[None, :, :] * (afac * ldir), axis=-1)
+    refl = -2 * np.sum(-ldir * fn[None, :, :], axis=-1)[..., None] * fn[None, :, :] - ldir
+    cdir = unit3(eye[None, None, :] - p[None, :, :])
+    rdotc = np.sum(cdir * refl, axis=-1)
+    if double_sided:
+        sgn = np.sign(np.sum(cdir * fn[None, :, :], axis=-1))
+        ndotl = sgn * ndotl
+        rdotc = sgn * rdotc
+    ndotl = np.maximum(ndotl, 0.0)
+    rdotc = np.maximum(rdotc, 0.0)
+    lav = lcol[:, None, :] * alb[None, :, :]
+    col = (cf[:, 0][None, :, None] * ndotl[:, :, None] +
+           cf[:, 1][None, :, None] * (rdotc[:, :, None] ** cf[:, 2][None, :, None])) * lav + \
+        ambient[None, None, :] * alb[None, :, :]
+    return np.sum(col, axis=0)
+
+
 def generate_rays(camera):
     """torch/utils.py:439-478 (perspective branch) with lookat_rot_inv (:402-427)."""
     vp = camera['viewport']
@@ -54,6 +170,8 @@ def render(scene, double_sided=False, use_quartic=False, tile=2048):
     """Returns image (H,W,3), depth (H,W) with far+1 background, nearest (H,W), normal (H,W,3), pos (H,W,3)
     (normal / pos are 0 where nothing is hit)."""
     cam = scene['camera']
+    if is_ortho(cam):
+        return _render_ortho(scene, double_sided, use_quartic)
     eye, ray_dir, H, W = generate_rays(cam)
     npix = H * W
     near, far = cam['near'], cam['far']
