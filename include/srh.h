@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 3
+#define SRH_ABI_VERSION 4
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -66,6 +66,9 @@ typedef struct SrhCamera {
   double near_clip;       /* valid hit: near <= t <= far on Euclidean ray distance (:219) */
   double far_clip;
   int32_t viewport[4];    /* x0, y0, x1, y1; W = x1 - x0, H = y1 - y0 */
+  int32_t ortho;          /* 1: orthographic projection (torch/utils.py:461-468) -- SRH_SHADING_TORCH only (the numpy
+                             backend has none), forward only, all pairs in fp64; 0: perspective */
+  int32_t pad;
 } SrhCamera;
 
 /* one entry of scene['objects']: a batch of primitives of one type (device pointers) */

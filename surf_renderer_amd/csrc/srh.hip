@@ -230,6 +230,41 @@ __global__ __launch_bounds__(256) void k_render_exact(FrameDev F, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_render_ortho: orthographic projection of the torch backend (torch/utils.py:461-468): every ray has the direction
+// -z of the camera basis and its own origin eye + x X + y Y.  All pairs in fp64 (the screen-space reject records are
+// derived for a pinhole); the reference's own ortho branch only works for images below one 4096-pixel tile.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_render_ortho(FrameDev F, float* __restrict__ image,
+                                                       float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r = F.row0 + blockIdx.y * 4 + threadIdx.y;
+  const bool live = (c < F.W) && (r < F.row1);
+  const int cc = live ? c : F.W - 1, rr = live ? r : F.row1 - 1;
+  const double xs = (F.W > 1 && cc == F.W - 1) ? 1.0 : (cc * F.step_x + -1.0);
+  const double ys = (F.H > 1 && rr == F.H - 1) ? -1.0 : (rr * F.step_y + 1.0);
+  const double X = xs * F.half_w, Y = ys * F.half_h;
+  double q[3], org[3], d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    q[i] = F.bx[i] * X + F.by[i] * Y;
+    org[i] = F.o[i] + q[i];
+    d[i] = -F.bz[i];
+  }
+  double best = __builtin_inf();
+  int besti = 0;
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+    const int stride = kRec64Stride[S.type];
+    for (int i = 0; i < S.count; ++i)
+      resolve(F, hit_any64_from(S.type, S.rec64 + (size_t)i * stride, F.o, q, d), S.first + i, best, besti);
+  }
+  float rgb[3], aux[6];
+  const bool want_aux = F.normal_out || F.pos_out;
+  shade_pixel_t<true>(F, d, best, besti, rgb, want_aux ? aux : nullptr, nullptr, org);
+  if (live) store_pixel(F, c, r, rgb, best, besti, image, depth, nearest, want_aux ? aux : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_render_fast<P>: fp32 screen-space reject per pair, fp64 confirmation of the survivors.
 // A wave owns 64*P consecutive pixels of one row: lane l holds columns c0 + l + 64*j, j < P.  Reject
 // records are wave-uniform reads (scalar loads); the survivor branch is entered by a wave only when one
@@ -462,6 +497,7 @@ int camera_to_frame(const SrhCamera* cam, FrameDev* F, bool orthonormal = false)
   ok = false;
 #endif
   F->div_shared = ok ? 1 : 0;
+  F->ortho = cam->ortho ? 1 : 0;
   return SRH_OK;
 }
 
@@ -567,6 +603,7 @@ int srh_generate_rays(const SrhCamera* camera, int32_t row0, int32_t row1, float
   FrameDev F;
   memset(&F, 0, sizeof(F));
   int rc = camera_to_frame(camera, &F);
+  if (rc == SRH_OK && F.ortho) rc = fail(SRH_E_CAMERA, "srh_generate_rays: perspective cameras only");
   if (rc) return rc;
   if ((rc = check_rows(F, row0, row1))) return rc;
   if (!ray_dir) return fail(SRH_E_NULL, "ray_dir is NULL");
@@ -617,7 +654,10 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   int rc = setup_frame(camera, objects, lights, materials, params, workspace, workspace_bytes, &F, &L);
   if (rc) return rc;
   if (!image || !depth) return fail(SRH_E_NULL, "image / depth is NULL");
-  const int mode = params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode;
+  if (F.ortho && params->shading != SRH_SHADING_TORCH)
+    return fail(SRH_E_CAMERA, "orthographic projection exists only under SRH_SHADING_TORCH");
+  // orthographic frames take the all-pairs fp64 kernel of their own, whatever mode is asked for
+  const int mode = F.ortho ? SRH_MODE_EXACT : (params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode);
   hipStream_t st = (hipStream_t)stream;
   if (mode == SRH_MODE_BINNED) {
     setup_binning(F, L, workspace);
@@ -650,7 +690,8 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     }
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
-    hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
+    if (F.ortho) hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, image, depth, nearest);
+    else hipLaunchKernelGGL(k_render_exact, grid, block, 0, st, F, image, depth, nearest);
   } else if (F.W >= 2048) {
     launch_fast<8>(F, st, image, depth, nearest);
   } else if (F.W >= 512) {
@@ -721,6 +762,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     int rc = setup_frame(&cameras[v], objects, lights, materials, params, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
     if (F.row0 != 0 || F.row1 != F.H) return fail(SRH_E_RANGE, "srh_render_views renders whole frames (rows 0..H)");
+    if (F.ortho) return fail(SRH_E_CAMERA, "srh_render_views: perspective cameras only");
     setup_binning(F, L, ws + head + (size_t)v * one);
   }
   const FrameDev* Fs = (const FrameDev*)ws;
@@ -761,6 +803,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (rc) return rc;
   if (!grad_image || !nearest || !depth || !grads)
     return fail(SRH_E_NULL, "grad_image / nearest / depth / grads is NULL");
+  if (F.ortho) return fail(SRH_E_CAMERA, "orthographic frames are forward only");
   GradsDev G;
   for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) {
     G.pos[s] = grads->pos[s]; G.normal[s] = grads->normal[s]; G.radius[s] = grads->radius[s]; G.face[s] = grads->face[s];

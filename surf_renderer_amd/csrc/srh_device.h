@@ -45,6 +45,7 @@ struct FrameDev {
   // SRH_SHADING_TORCH extras (torch/renderer.py:82-125)
   int32_t shading, double_sided, use_quartic;
   int32_t div_shared;                // pixel_ray may share one reciprocal between its three divisions (see there)
+  int32_t ortho, pad4;               // orthographic projection (torch semantics only; k_render_ortho)
   const float* latt;                 // (L,3) attenuation or NULL
   const float* coeffs;               // (K,3) material coefficients or NULL
   const float* ambient;              // (3) or NULL
@@ -201,6 +202,36 @@ __device__ __forceinline__ double hit_any64(int type, const double* R, const dou
   }
 }
 
+// The same intersections for a ray that starts at eye + q instead of at the eye (orthographic projection, torch
+// semantics): the eye-relative records shift by q -- k' = k - n^.q, oc' = oc + q, |oc'|^2 - r^2 = c + 2 oc.q + |q|^2.
+__device__ __forceinline__ double hit_any64_from(int type, const double* R, const double o[3], const double q[3],
+                                                 const double d[3]) {
+  if (type == SRH_PRIM_SPHERE) {
+    const double oc[3] = {R[0] + q[0], R[1] + q[1], R[2] + q[2]};
+    const double Rs[4] = {oc[0], oc[1], oc[2], (R[3] + 2.0 * dot3(R, q)) + dot3(q, q)};
+    return hit_sphere64_tch(Rs, d);
+  }
+  const double t = (R[3] - dot3(R, q)) / dot3(R, d);
+  if (type == SRH_PRIM_PLANE) return t;
+  if (type == SRH_PRIM_DISK) {
+    const double qx = (R[4] + q[0]) + t * d[0], qy = (R[5] + q[1]) + t * d[1], qz = (R[6] + q[2]) + t * d[2];
+    return ((qx * qx + qy * qy) + qz * qz <= R[7]) ? t : __builtin_inf();
+  }
+  const double p[3] = {(o[0] + q[0]) + t * d[0], (o[1] + q[1]) + t * d[1], (o[2] + q[2]) + t * d[2]};
+  bool inside = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double* v = R + 4 + 3 * i;
+    const double* e = R + 13 + 3 * i;
+    const double w[3] = {p[0] - v[0], p[1] - v[1], p[2] - v[2]};
+    const double cx = e[1] * w[2] - e[2] * w[1];
+    const double cy = e[2] * w[0] - e[0] * w[2];
+    const double cz = e[0] * w[1] - e[1] * w[0];
+    inside = inside && (((cx * R[0] + cy * R[1]) + cz * R[2]) >= 0.0);
+  }
+  return inside ? t : __builtin_inf();
+}
+
 // numpy/renderer.py:219-223: a hit is valid iff near <= t <= far; the running minimum only moves on
 // a strictly smaller t, so the lowest global index wins ties exactly like np.argmin.
 __device__ __forceinline__ void resolve(const FrameDev& F, double t, int gidx, double& best, int& besti) {
@@ -273,7 +304,8 @@ struct ShadeHint {
 
 template <bool TCH>
 __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
-                                              float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr) {
+                                              float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr,
+                                              const double* origin = nullptr) {
   const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
   if (aux) {
 #pragma unroll
@@ -289,7 +321,8 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     if (i < F.nseg && win >= F.seg[i].first) s = i;
   const SegDev& S = F.seg[s];
   const int li = win - S.first;
-  const double p[3] = {F.o[0] + z * d[0], F.o[1] + z * d[1], F.o[2] + z * d[2]};
+  const double* org = origin ? origin : F.o;     // orthographic rays start on the image plane, not at the eye
+  const double p[3] = {org[0] + z * d[0], org[1] + z * d[1], org[2] + z * d[2]};
 
   double n[3];
   if (S.type == SRH_PRIM_SPHERE) {

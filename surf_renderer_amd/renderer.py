@@ -247,8 +247,11 @@ def camera_struct(camera: Dict[str, Any]) -> _lib.SrhCamera:
     vp = [int(v) for v in np.ravel(_host_view(camera["viewport"]) if not isinstance(camera["viewport"], torch.Tensor)
                                    else camera["viewport"].cpu().numpy())]
     cam.viewport[:] = vp
-    if str(camera.get("proj_type", "perspective")) != "perspective":
-        raise NotImplementedError("the numpy backend, which this backend matches, is perspective-only")
+    proj = str(camera.get("proj_type", "perspective"))
+    if proj in ("ortho", "orthographic"):
+        cam.ortho = 1                    # torch/utils.py:461: only the torch backend's semantics have it
+    elif proj not in ("persp", "perspective"):
+        raise ValueError(f"camera.proj_type {proj!r}: expected 'perspective' or 'ortho'")
     return cam
 
 
@@ -523,6 +526,11 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     if params.get("shadow"):
         raise NotImplementedError("shadow rays (torch/renderer.py:291-314) are not implemented by the hip backend")
     inputs = [buf.tensors[k] for k in _float_keys(buf, shading)]
+    if cam.ortho:
+        if shading != "torch":
+            raise ValueError("orthographic projection exists only in the torch backend's semantics: shading='torch'")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
+            raise NotImplementedError("orthographic projection is forward only")
     if shading == "torch":
         # the torch backend's semantics
         shade = ("torch", bool(params.get("double_sided", False)), bool(params.get("use_quartic", False)))

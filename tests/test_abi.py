@@ -44,7 +44,7 @@ def test_abi_version_matches_header(lib):
 
 def test_struct_layouts_match_the_header():
     # natural C layout of the declarations in srh.h (LP64)
-    assert C.sizeof(_lib.SrhCamera) == 3 * 32 + 4 * 8 + 16
+    assert C.sizeof(_lib.SrhCamera) == 3 * 32 + 4 * 8 + 16 + 8
     assert C.sizeof(_lib.SrhSegment) == 8 + 5 * 8
     assert C.sizeof(_lib.SrhObjects) == 8 + _lib.MAX_SEGMENTS * C.sizeof(_lib.SrhSegment)
     assert C.sizeof(_lib.SrhLights) == 8 + 5 * 8

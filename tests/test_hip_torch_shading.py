@@ -55,3 +55,23 @@ def test_torch_shading_modes_identical_and_numpy_default_unchanged():
     assert "normal" not in plain and torch.isinf(plain["depth"]).any()
     with pytest.raises(NotImplementedError):
         render(scene, device="cuda:0", shading="torch", shadow=True)
+
+
+def test_orthographic_projection_rules():
+    """proj_type 'ortho' exists in the torch backend only: the numpy shading model refuses it, gradients are not
+    offered, the stream-batched views refuse it; the frame itself is covered by the t4 / t5 fixtures above."""
+    from surf_renderer_amd import render, render_views
+    scene, _, kw = load_tch_case("t4_mixed_ortho_64x48")
+    with pytest.raises(ValueError):
+        render(scene, device="cuda:0")
+    leaf = dict(scene, materials=dict(scene["materials"]))
+    leaf["materials"]["albedo"] = torch.tensor(np.asarray(scene["materials"]["albedo"], dtype=np.float32), requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        render(leaf, device="cuda:0", shading="torch")
+    with pytest.raises(RuntimeError):
+        render_views(scene, [scene["camera"]], device="cuda:0", shading="torch")
+    # a row slab of the orthographic frame equals the rows of the full frame
+    full = _render(scene, **kw)
+    part = _render(scene, rows=(10, 31), **kw)
+    for k in ("image", "depth", "nearest"):
+        np.testing.assert_array_equal(part[k], full[k][10:31])
