@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 4
+#define SRH_ABI_VERSION 5
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -131,6 +131,8 @@ typedef struct SrhParams {
   int64_t nearest_row_stride;   /* multi-GPU frame is collected by a single gather. */
   void* ev_start;               /* optional hipEvent_t pair recorded on `stream` immediately before and */
   void* ev_stop;                /* after the frame's dominant kernel (measurement hook); NULL = off */
+  const void* visibility;       /* srh_render_bwd, SRH_SHADING_TORCH: the (rows,W) uint64 light-visibility bits that
+                                   srh_shadow_shade wrote for this frame, or NULL (no shadows) */
 } SrhParams;
 
 int srh_abi_version(void);
@@ -198,6 +200,15 @@ size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32
 int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
                      float* images, float* depths, int32_t* nearests, void* stream);
+
+/* The torch backend's `shadow=True` (diffrend/torch/renderer.py:291-314) as a second pass over a frame rendered by
+ * srh_render_fwd with the same camera / scene / params (SRH_SHADING_TORCH): per hit pixel and light a shadow ray from
+ * the fragment (started 0.1 towards the light) against every primitive, all pairs in fp64; a light is visible unless
+ * a primitive other than the fragment's own is hit before it.  `image` (rows,W,3) is overwritten with the re-shaded
+ * frame; `visibility` (rows,W) uint64, bit l = light l visible, may be NULL.  O(pixels x lights x primitives). */
+int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                     const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                     const int32_t* nearest, const float* depth, float* image, uint64_t* visibility, void* stream);
 
 /* measurement helpers: timing-enabled HIP events usable as SrhParams.ev_start / ev_stop.
  * srh_event_elapsed_ms waits for `stop` to complete (the only call here that blocks the host). */

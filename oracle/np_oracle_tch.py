@@ -1,7 +1,7 @@
 """CPU oracle for the reference's *torch* backend semantics -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-fp64 numpy restatement of the forward of ``diffrend/torch/renderer.py:136-355`` (perspective projection, no
-shadows), the superset shading model that the hip backend offers as ``render(scene, shading='torch')``
+fp64 numpy restatement of the forward of ``diffrend/torch/renderer.py:136-355`` (perspective and orthographic
+projection; shadows as an UNPINNED extra, see light_visibility), the superset shading model that the hip backend offers as ``render(scene, shading='torch')``
 (SURVEY.md section 8, row f1).  Differences from the numpy backend that this file reproduces:
   * camera basis orthonormalised: x = unit(cross(unit(up), z)), y = cross(z, x)        (torch/utils.py:402-427)
   * normals normalised over xyz only, with the reference's eps: u / sqrt(sum(u^2 + 1e-10))   (torch/utils.py:131-135)
@@ -53,6 +53,87 @@ def generate_rays_ortho(camera):
     return eye, orig, unit3(at - eye), H, W
 
 
+def _hits_general(segs, total, orig, dirs):
+    """Ray distances (M,n) of rays with their own origins `orig` (n,3) and directions `dirs` (n,3) against every
+    primitive, torch semantics (torch/utils.py:238-366) with this oracle's two deviations: a miss is +inf, a
+    negative sphere root is a miss."""
+    n = orig.shape[0]
+    t_all = np.empty((total, n))
+    for kind, start, count, g in segs:
+        if kind == 'sphere':
+            oc = orig[None, :, :] - g['pos'][:, None, :3]                          # (M,n,3)
+            a = np.sum(dirs ** 2, axis=-1)[None, :]
+            b = 2 * np.sum(oc * dirs[None, :, :], axis=-1)
+            c = np.sum(oc ** 2, axis=-1) - (g['radius'] ** 2)[:, None]
+            disc = b ** 2 - 4 * a * c
+            ok = disc >= 0
+            root = np.sqrt(np.where(ok, disc, 0.0))
+            t1 = (-b - root) / (2 * a)
+            t2 = (-b + root) / (2 * a)
+            t = np.minimum(np.where(ok & (t1 >= 0), t1, np.inf), np.where(ok & (t2 >= 0), t2, np.inf))
+        else:
+            nrm = unit3(g['normal'][:, :3])
+            q = g['face'][:, 0, :3] if kind == 'triangle' else g['pos'][:, :3]
+            den = nrm @ dirs.T                                                     # (M,n)
+            t = (np.sum(q * nrm, axis=1)[:, None] - nrm @ orig.T) / den
+            p = orig[None, :, :] + t[:, :, None] * dirs[None, :, :]
+            if kind == 'disk':
+                inside = np.sum((p - g['pos'][:, None, :3]) ** 2, axis=-1) <= (g['radius'] ** 2)[:, None]
+                t = np.where(inside, t, np.inf)
+            elif kind == 'triangle':
+                inside = np.ones_like(t, dtype=bool)
+                for i in range(3):
+                    edge = (g['face'][:, (i + 1) % 3, :3] - g['face'][:, i, :3])[:, None, :]
+                    rel = p - g['face'][:, i, :3][:, None, :]
+                    inside &= np.sum(np.cross(edge, rel) * nrm[:, None, :], axis=-1) >= 0
+                t = np.where(inside, t, np.inf)
+        t_all[start:start + count] = t
+    return t_all
+
+
+def light_visibility(scene, res):
+    """torch/renderer.py:291-314 (`shadow=True`): from every fragment a ray towards every light, started 0.1 along
+    it; the light is visible unless some primitive OTHER than the fragment's own is hit closer than the light
+    (distances measured from the shifted origin, the light's distance from the fragment itself, as the reference
+    does).  Returns (L, H*W) bool.  PARITY UNPINNED: the reference casts the result with
+    `.type(torch.cuda.FloatTensor)`, so its shadow path cannot run without CUDA and no fixture could be generated."""
+    cam = scene['camera']
+    objs = {k: {f: np.asarray(v, dtype=np.float64) if f != 'material_idx' else np.asarray(v) for f, v in g.items()}
+            for k, g in scene['objects'].items()}
+    segs, total = np_oracle._segments(objs)
+    p = res['pos'].reshape(-1, 3)
+    nearest = res['nearest'].reshape(-1)
+    lpos = np.asarray(scene['lights']['pos'], dtype=np.float64)[:, :3]
+    vis = np.ones((lpos.shape[0], p.shape[0]), dtype=bool)
+    with np.errstate(all='ignore'):
+        for l in range(lpos.shape[0]):
+            v = lpos[l][None, :] - p
+            dist = np.sqrt(np.sum(v ** 2, axis=-1))
+            dirs = v / dist[:, None]
+            t = _hits_general(segs, total, p + 0.1 * dirs, dirs)
+            t = np.where((t > 0) & (t < dist[None, :]), t, np.inf)
+            blocker = np.argmin(t, axis=0)
+            vis[l] = ~np.isfinite(t[blocker, np.arange(p.shape[0])]) | (blocker == nearest)
+    return vis
+
+
+def shade(scene, res, vis=None, double_sided=False, use_quartic=False):
+    """The image (H,W,3) of a frame whose geometry buffers (`pos`, `normal`, `nearest`, `depth`) are in `res`, with
+    optional light visibility (L, H*W)."""
+    cam = scene['camera']
+    H, W = res['depth'].shape
+    hit = (res['depth'] <= cam['far']).reshape(-1)
+    material_idx = np.concatenate([np.asarray(g['material_idx']) for g in scene['objects'].values()]).astype(np.int64)
+    eye = np.asarray(cam['eye'], dtype=np.float64)[:3]
+    with np.errstate(all='ignore'):
+        im = _fragment_shader(scene, eye, res['pos'].reshape(-1, 3), res['normal'].reshape(-1, 3),
+                              material_idx[res['nearest'].reshape(-1)], double_sided, use_quartic, vis)
+        im = np.maximum(np.where(hit[:, None], im, 0.0), 0.0)
+        if 'tonemap' in scene:
+            im = im ** float(np.ravel(scene['tonemap']['gamma'])[0])
+    return im.reshape(H, W, 3)
+
+
 def _render_ortho(scene, double_sided, use_quartic):
     """The orthographic frame: same pipeline as `render` with per-ray origins and one direction."""
     cam = scene['camera']
@@ -63,36 +144,8 @@ def _render_ortho(scene, double_sided, use_quartic):
             for k, g in scene['objects'].items()}
     segs, total = np_oracle._segments(objs)
     material_idx = np.concatenate([g['material_idx'] for _, _, _, g in segs], axis=0).astype(np.int64)
-    t_all = np.empty((total, npix))
     with np.errstate(all='ignore'):
-        for kind, start, count, g in segs:
-            if kind == 'sphere':
-                oc = orig[None, :, :] - g['pos'][:, None, :3]                      # (M,N,3)
-                b = 2 * np.sum(oc * dvec[None, None, :], axis=-1)
-                c = np.sum(oc ** 2, axis=-1) - (g['radius'] ** 2)[:, None]
-                disc = b ** 2 - 4 * c
-                ok = disc >= 0
-                root = np.sqrt(np.where(ok, disc, 0.0))
-                t1 = (-b - root) / 2
-                t2 = (-b + root) / 2
-                t = np.minimum(np.where(ok & (t1 >= 0), t1, np.inf), np.where(ok & (t2 >= 0), t2, np.inf))
-            else:
-                nrm = unit3(g['normal'][:, :3])
-                q = g['face'][:, 0, :3] if kind == 'triangle' else g['pos'][:, :3]
-                den = nrm @ dvec                                                  # (M,)
-                t = (np.sum(q * nrm, axis=1)[:, None] - nrm @ orig.T) / den[:, None]
-                p = orig[None, :, :] + t[:, :, None] * dvec[None, None, :]
-                if kind == 'disk':
-                    inside = np.sum((p - g['pos'][:, None, :3]) ** 2, axis=-1) <= (g['radius'] ** 2)[:, None]
-                    t = np.where(inside, t, np.inf)
-                elif kind == 'triangle':
-                    inside = np.ones_like(t, dtype=bool)
-                    for i in range(3):
-                        edge = (g['face'][:, (i + 1) % 3, :3] - g['face'][:, i, :3])[:, None, :]
-                        rel = p - g['face'][:, i, :3][:, None, :]
-                        inside &= np.sum(np.cross(edge, rel) * nrm[:, None, :], axis=-1) >= 0
-                    t = np.where(inside, t, np.inf)
-            t_all[start:start + count] = t
+        t_all = _hits_general(segs, total, orig, np.broadcast_to(dvec[None, :], orig.shape))
         valid = (near <= t_all) & (t_all <= far)
         t_all[~valid] = np.inf
         win = np.argmin(t_all, axis=0)
@@ -114,8 +167,9 @@ def _render_ortho(scene, double_sided, use_quartic):
             'pos': np.where(hit[:, None], p, 0.0).reshape(H, W, 3)}
 
 
-def _fragment_shader(scene, eye, p, fn, mat, double_sided, use_quartic):
-    """torch/renderer.py:82-125 for fragments p (n,3) with normals fn (n,3) and material indices mat (n,)."""
+def _fragment_shader(scene, eye, p, fn, mat, double_sided, use_quartic, vis=None):
+    """torch/renderer.py:82-125 for fragments p (n,3) with normals fn (n,3) and material indices mat (n,);
+    `vis` (L,n) multiplies the light-times-albedo term (:116-118), not the ambient one."""
     lpos = np.asarray(scene['lights']['pos'], dtype=np.float64)[:, :3]
     lcol = np.asarray(scene['colors'], dtype=np.float64)[np.asarray(scene['lights']['color_idx'])]
     att = np.asarray(scene['lights']['attenuation'], dtype=np.float64)
@@ -139,6 +193,8 @@ def _fragment_shader(scene, eye, p, fn, mat, double_sided, use_quartic):
     ndotl = np.maximum(ndotl, 0.0)
     rdotc = np.maximum(rdotc, 0.0)
     lav = lcol[:, None, :] * alb[None, :, :]
+    if vis is not None:
+        lav = lav * np.asarray(vis, dtype=np.float64)[:, :, None]
     col = (cf[:, 0][None, :, None] * ndotl[:, :, None] +
            cf[:, 1][None, :, None] * (rdotc[:, :, None] ** cf[:, 2][None, :, None])) * lav + \
         ambient[None, None, :] * alb[None, :, :]
@@ -166,9 +222,16 @@ def generate_rays(camera):
     return eye, d, H, W
 
 
-def render(scene, double_sided=False, use_quartic=False, tile=2048):
+def render(scene, double_sided=False, use_quartic=False, tile=2048, shadow=False):
     """Returns image (H,W,3), depth (H,W) with far+1 background, nearest (H,W), normal (H,W,3), pos (H,W,3)
-    (normal / pos are 0 where nothing is hit)."""
+    (normal / pos are 0 where nothing is hit).  With `shadow` also `visibility` (L,H,W) bool, and the image is
+    shaded with it (see light_visibility: that part of the oracle is UNPINNED)."""
+    if shadow:
+        res = render(scene, double_sided, use_quartic, tile)
+        vis = light_visibility(scene, res)
+        res['image'] = shade(scene, res, vis, double_sided, use_quartic)
+        res['visibility'] = vis.reshape((-1,) + res['depth'].shape)
+        return res
     cam = scene['camera']
     if is_ortho(cam):
         return _render_ortho(scene, double_sided, use_quartic)

@@ -161,7 +161,7 @@ def _unit3_eps(v: torch.Tensor) -> torch.Tensor:
 
 
 def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Optional[Dict[str, np.ndarray]] = None,
-               double_sided: bool = False, use_quartic: bool = False):
+               double_sided: bool = False, use_quartic: bool = False, visibility: Optional[np.ndarray] = None):
     """Differentiable image (H,W,3), depth (H,W) and hit mask under the torch backend's semantics
     (diffrend/torch/renderer.py:82-125,136-355; see oracle/np_oracle_tch.py for the forward restatement and its two
     documented deviations).  Selection and every mask (per-light relu, double_sided sign, clip) are piecewise
@@ -236,6 +236,8 @@ def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Opti
     rdotc = torch.relu(rdotc)
     spec = cf[:, None, 1] * rdotc ** cf[:, None, 2]                          # torch.pow: 0 ** 0 = 1, masked gradients at 0
     w = cf[:, None, 0] * ndotl + spec                                        # (N,L)
+    if visibility is not None:                                               # (L,N) constants: shadow rays
+        w = w * torch.as_tensor(np.asarray(visibility, dtype=np.float64).reshape(w.shape[1], -1).T)
     col = w[:, :, None] * (lcol[None, :, :] * alb[:, None, :]) + amb[None, None, :] * alb[:, None, :]
     im = torch.sum(col, dim=1)
     im = torch.where(hit[:, None], im, torch.zeros_like(im))
@@ -249,9 +251,9 @@ def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Opti
 
 def gradients_tch(scene: Dict[str, Any], grad_image: np.ndarray, grad_depth: Optional[np.ndarray] = None,
                   ref: Optional[Dict[str, np.ndarray]] = None, double_sided: bool = False,
-                  use_quartic: bool = False) -> Dict[str, np.ndarray]:
+                  use_quartic: bool = False, visibility: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
     leaves = make_leaves_tch(scene)
-    image, depth, hit = render_tch(scene, leaves, ref, double_sided, use_quartic)
+    image, depth, hit = render_tch(scene, leaves, ref, double_sided, use_quartic, visibility)
     loss = torch.sum(image * torch.as_tensor(grad_image))
     if grad_depth is not None:
         gd = torch.as_tensor(grad_depth)

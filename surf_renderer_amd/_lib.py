@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -54,7 +54,7 @@ class SrhParams(C.Structure):
                 ("normal_out", C.c_void_p), ("pos_out", C.c_void_p),
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("visibility", C.c_void_p)]
 
 
 class SrhGrads(C.Structure):
@@ -65,7 +65,7 @@ class SrhGrads(C.Structure):
 
 
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
-           "srh_render_bwd", "srh_workspace_bytes_views", "srh_render_views",
+           "srh_render_bwd", "srh_workspace_bytes_views", "srh_render_views", "srh_shadow_shade",
            "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
@@ -118,6 +118,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_render_views.argtypes = [C.c_int32, C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                      C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srh_shadow_shade.restype = C.c_int
+    lib.srh_shadow_shade.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
+                                     C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.srh_event_create.restype = C.c_int
     lib.srh_event_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.srh_event_destroy.restype = C.c_int

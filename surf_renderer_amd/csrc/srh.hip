@@ -265,6 +265,75 @@ __global__ __launch_bounds__(256) void k_render_ortho(FrameDev F, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_shadow_shade: the torch backend's `shadow=True` (torch/renderer.py:291-314) as a second pass over a rendered
+// frame.  Per hit pixel and light a ray from the fragment towards the light, started 0.1 along it, against EVERY
+// primitive in fp64 (arbitrary origins and directions: no screen-space structure to exploit, and the reference is
+// all-pairs too); the light counts as visible unless a primitive other than the fragment's own is hit before the
+// light.  Then the pixel is shaded again with the visibility bits and the image is overwritten.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shadow_shade(FrameDev F, float* __restrict__ image,
+                                                       const float* __restrict__ depth,
+                                                       const int32_t* __restrict__ nearest,
+                                                       uint64_t* __restrict__ visibility) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int r = F.row0 + blockIdx.y * 4 + threadIdx.y;
+  if (c >= F.W || r >= F.row1) return;
+  const size_t row = (size_t)(r - F.row0);
+  const bool hit = (double)depth[row * F.depth_stride + c] <= F.far_clip;
+  uint64_t vis = ~0ull;
+  if (!hit) {                                               // background: nothing to shade, every bit set
+    if (visibility) visibility[row * (size_t)F.W + c] = vis;
+    return;
+  }
+  const int win = nearest[row * F.near_stride + c];
+  const int s = segment_of(F, win);
+  const SegDev& S = F.seg[s];
+  const double* R = S.rec64 + (size_t)(win - S.first) * kRec64Stride[S.type];
+  // the primary ray and its hit, exactly as the forward pass computed them
+  double d[3], q0[3] = {0, 0, 0}, org[3];
+  double t;
+  if (F.ortho) {
+    const double xs = (F.W > 1 && c == F.W - 1) ? 1.0 : (c * F.step_x + -1.0);
+    const double ys = (F.H > 1 && r == F.H - 1) ? -1.0 : (r * F.step_y + 1.0);
+    const double X = xs * F.half_w, Y = ys * F.half_h;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q0[i] = F.bx[i] * X + F.by[i] * Y; d[i] = -F.bz[i]; }
+    t = hit_any64_from(S.type, R, F.o, q0, d);
+  } else {
+    pixel_ray(F, c, r, d);
+    t = hit_any64(S.type, R, F.o, d, true);
+  }
+  double p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { org[i] = F.o[i] + q0[i]; p[i] = org[i] + t * d[i]; }
+
+  vis = 0ull;
+  for (int l = 0; l < F.nlights; ++l) {
+    const float* lp = F.lpos + 4 * l;
+    const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
+    const double dist = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const double dir[3] = {v[0] / dist, v[1] / dist, v[2] / dist};
+    const double q[3] = {(p[0] + 0.1 * dir[0]) - F.o[0], (p[1] + 0.1 * dir[1]) - F.o[1], (p[2] + 0.1 * dir[2]) - F.o[2]};
+    double tmin = __builtin_inf();
+    int blocker = -1;
+    for (int sg = 0; sg < F.nseg; ++sg) {
+      const SegDev& B = F.seg[sg];
+      const int stride = kRec64Stride[B.type];
+      for (int i = 0; i < B.count; ++i) {
+        const double ts = hit_any64_from(B.type, B.rec64 + (size_t)i * stride, F.o, q, dir);
+        if (ts > 0.0 && ts < dist && ts < tmin) { tmin = ts; blocker = B.first + i; }   // lowest index wins ties
+      }
+    }
+    if (blocker < 0 || blocker == win) vis |= 1ull << l;
+  }
+  float rgb[3];
+  shade_pixel_t<true>(F, d, t, win, rgb, nullptr, nullptr, org, vis);
+  float* px = image + row * F.img_stride + 3 * (size_t)c;
+  px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
+  if (visibility) visibility[row * (size_t)F.W + c] = vis;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_render_fast<P>: fp32 screen-space reject per pair, fp64 confirmation of the survivors.
 // A wave owns 64*P consecutive pixels of one row: lane l holds columns c0 + l + 64*j, j < P.  Reject
 // records are wave-uniform reads (scalar loads); the survivor branch is entered by a wave only when one
@@ -793,6 +862,28 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   return e == hipSuccess ? SRH_OK : hip_fail(e, "views launch");
 }
 
+int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
+                     const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
+                     const int32_t* nearest, const float* depth, float* image, uint64_t* visibility, void* stream) {
+  FrameDev F;
+  WsLayout L;
+  int rc = setup_frame(camera, objects, lights, materials, params, workspace, workspace_bytes, &F, &L);
+  if (rc) return rc;
+  if (!nearest || !depth || !image) return fail(SRH_E_NULL, "nearest / depth / image is NULL");
+  if (params->shading != SRH_SHADING_TORCH)
+    return fail(SRH_E_TYPE, "shadow rays belong to SRH_SHADING_TORCH (the numpy backend has none)");
+  hipStream_t st = (hipStream_t)stream;
+  // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
+  for (int s = 0; s < F.nseg; ++s) {
+    const SegDev& S = F.seg[s];
+    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+  }
+  const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+  hipLaunchKernelGGL(k_shadow_shade, grid, block, 0, st, F, image, depth, nearest, visibility);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "shadow launch");
+}
+
 int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
                    const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
                    const float* grad_image, const float* grad_depth, const int32_t* nearest, const float* depth,
@@ -824,7 +915,8 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
-  if (tch) hipLaunchKernelGGL(k_render_bwd_tch, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
+  if (tch) hipLaunchKernelGGL(k_render_bwd_tch, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth,
+                              (const uint64_t*)params->visibility);
   else hipLaunchKernelGGL(k_render_bwd, grid, block, 0, st, F, G, grad_image, grad_depth, nearest, depth);
   if (params->ev_stop) (void)hipEventRecord((hipEvent_t)params->ev_stop, st);
   hipError_t e = hipGetLastError();

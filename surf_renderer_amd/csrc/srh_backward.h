@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
 __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
                                                          const float* __restrict__ grad_depth,
                                                          const int32_t* __restrict__ nearest,
-                                                         const float* __restrict__ depth) {
+                                                         const float* __restrict__ depth,
+                                                         const uint64_t* __restrict__ visibility) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   const int r = F.row0 + blockIdx.y * 4 + threadIdx.y;
   const int lane = threadIdx.x;
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
       nrm_base = F.seg[i].normal; rad_base = F.seg[i].radius; face_base = F.seg[i].face; mat_base = F.seg[i].mat;
     }
   const int li = win - first;
+  // light visibility of the forward pass (shadow rays): a constant 0 / 1 factor on each light's colour x albedo term
+  const uint64_t vis = (visibility && hit) ? visibility[row * (size_t)F.W + cc] : ~0ull;
 
   double d[3] = {0, 0, -1};
   pixel_ray(F, live ? c : 0, live ? r : F.row0, d);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
   for (int l = 0; l < F.nlights; ++l) {
     LightTerms T;
     light_terms(l, T);
-    const double w = cf[0] * fmax(T.nd, 0.0) + cf[1] * spec_pow(fmax(T.rd, 0.0));
+    const double w = (cf[0] * fmax(T.nd, 0.0) + cf[1] * spec_pow(fmax(T.rd, 0.0))) * (double)((vis >> l) & 1ull);
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + amb[ch] * alb[ch];
@@ -397,7 +400,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
     light_terms(l, T);
     const double ndotl = fmax(T.nd, 0.0), rdotc = fmax(T.rd, 0.0);
     const double P = spec_pow(rdotc);
-    const double w = cf[0] * ndotl + cf[1] * P;
+    const double vl = (double)((vis >> l) & 1ull);
+    const double w = (cf[0] * ndotl + cf[1] * P) * vl;         // the visible light's weight
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
     double g_w = 0.0, g_col[3];
 #pragma unroll
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
       g_col[ch] = g_im[ch] * w * alb[ch];
       g_amb[ch] += g_im[ch] * alb[ch];
     }
+    g_w *= vl;                                                  // d im / d (unshadowed weight)
     g_cf[0] += g_w * ndotl;
     g_cf[1] += g_w * P;
     if (rdotc > 0.0) g_cf[2] += g_w * cf[1] * P * log(rdotc);

@@ -305,7 +305,7 @@ struct ShadeHint {
 template <bool TCH>
 __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
                                               float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr,
-                                              const double* origin = nullptr) {
+                                              const double* origin = nullptr, uint64_t vis = ~0ull) {
   const bool masked = (z < F.near_clip) || (z > F.far_clip);      // :256
   if (aux) {
 #pragma unroll
@@ -380,7 +380,8 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
       ndotl = fmax(ndotl, 0.0);
       rdotc = fmax(rdotc, 0.0);
       const double spec = (cf[1] != 0.0) ? cf[1] * pow(rdotc, cf[2]) : 0.0;
-      const double w = cf[0] * ndotl + spec;
+      // light visibility (shadow rays, :116-118) multiplies light colour x albedo, not the ambient term
+      const double w = (cf[0] * ndotl + spec) * (double)((vis >> l) & 1ull);
       const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)      // the ambient term is added once per light, as the reference does (:116-121)

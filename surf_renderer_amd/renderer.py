@@ -344,6 +344,27 @@ def _float_keys(buf: SceneBuffers, shading: str = "numpy") -> List[str]:
     return keys
 
 
+def shadow_pass(buf: SceneBuffers, cam: _lib.SrhCamera, rows, image: torch.Tensor, depth: torch.Tensor,
+                nearest: torch.Tensor, double_sided: bool = False, use_quartic: bool = False) -> torch.Tensor:
+    """The torch backend's ``shadow=True`` (torch/renderer.py:291-314) over a frame rendered with
+    ``shading='torch'``: re-shades ``image`` in place with per-light visibility from all-pairs shadow rays and returns
+    the (rows, W) int64 visibility bit field (bit l = light l visible)."""
+    lib = _lib.load()
+    width, height = frame_size(cam)
+    r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
+    vis = torch.empty((r1 - r0, width), dtype=torch.int64, device=buf.device)
+    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES["auto"],
+                            tonemap_gamma=0 if buf.gamma is None else 1,
+                            gamma=1.0 if buf.gamma is None else buf.gamma, shading=_lib.SHADING["torch"],
+                            double_sided=int(bool(double_sided)), use_quartic=int(bool(use_quartic)))
+    workspace = buf.ensure_workspace(width, height)
+    with torch.cuda.device(buf.device):
+        _lib.check(lib.srh_shadow_shade(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                        C.byref(params), workspace.data_ptr(), workspace.numel(), nearest.data_ptr(),
+                                        depth.data_ptr(), image.data_ptr(), vis.data_ptr(), _stream_ptr(buf.device)))
+    return vis
+
+
 class _RenderFunction(torch.autograd.Function):
     """render_buffers with the analytic backward of libsrh (srh_render_bwd).  Gradient semantics are those of
     autograd through the reference's torch backend (SURVEY.md section 8, row a-B): selection and masks are piecewise
@@ -351,18 +372,26 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, buf, cam, rows, mode, shade, *inputs):
-        # shade = (shading, double_sided, use_quartic)
+        # shade = (shading, double_sided, use_quartic, shadow)
         image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode, shading=shade[0],
                                                double_sided=shade[1], use_quartic=shade[2])
+        vis = shadow_pass(buf, cam, rows, image, depth, nearest, shade[1], shade[2]) if shade[3] else None
         ctx.buf, ctx.cam, ctx.rows, ctx.mode, ctx.shade = buf, cam, rows, mode, shade
-        ctx.save_for_backward(depth, nearest)
+        ctx.has_vis = vis is not None
+        if vis is not None:
+            ctx.save_for_backward(depth, nearest, vis)
+        else:
+            ctx.save_for_backward(depth, nearest)
         ctx.mark_non_differentiable(nearest)
         return image, depth, nearest
 
     @staticmethod
     def backward(ctx, g_image, g_depth, _g_nearest):
         buf, cam = ctx.buf, ctx.cam
-        depth, nearest = ctx.saved_tensors
+        if ctx.has_vis:
+            depth, nearest, vis = ctx.saved_tensors
+        else:
+            (depth, nearest), vis = ctx.saved_tensors, None
         lib = _lib.load()
         width, height = frame_size(cam)
         r0, r1 = (0, height) if ctx.rows is None else (int(ctx.rows[0]), int(ctx.rows[1]))
@@ -400,7 +429,8 @@ class _RenderFunction(torch.autograd.Function):
                                 tonemap_gamma=0 if buf.gamma is None else 1,
                                 gamma=1.0 if buf.gamma is None else buf.gamma,
                                 shading=_lib.SHADING[ctx.shade[0]], double_sided=int(bool(ctx.shade[1])),
-                                use_quartic=int(bool(ctx.shade[2])))
+                                use_quartic=int(bool(ctx.shade[2])),
+                                visibility=vis.data_ptr() if vis is not None else None)
         workspace = buf.ensure_workspace(width, height)
         with torch.cuda.device(buf.device):
             rc = lib.srh_render_bwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
@@ -509,7 +539,8 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     ``validate`` (host-side index / w checks), ``shading`` ('numpy' | 'torch').  With ``shading='torch'`` the call
     follows ``diffrend.torch.renderer.render`` instead (Phong shading with lights.attenuation / lights.ambient /
     materials.coeffs, ``double_sided``, ``use_quartic``, orthonormal camera basis, far+1 background, extra outputs
-    ``normal`` and ``pos``; forward only).  The torch backend's remaining kwargs (tiled, tile_size, ...) are accepted
+    ``normal`` and ``pos``; ``shadow=True`` adds the all-pairs shadow-ray pass and a ``light_visibility`` bit field;
+    ``camera.proj_type = 'ortho'``).  The torch backend's remaining kwargs (tiled, tile_size, ...) are accepted
     and ignored.
     """
     unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate", "shading", "double_sided",
@@ -523,8 +554,9 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     shading = params.get("shading", "numpy")
     if shading not in _lib.SHADING:
         raise ValueError(f"shading must be 'numpy' or 'torch', got {shading!r}")
-    if params.get("shadow"):
-        raise NotImplementedError("shadow rays (torch/renderer.py:291-314) are not implemented by the hip backend")
+    shadow = bool(params.get("shadow", False))
+    if shadow and shading != "torch":
+        raise ValueError("shadow rays exist only in the torch backend's semantics: shading='torch'")
     inputs = [buf.tensors[k] for k in _float_keys(buf, shading)]
     if cam.ortho:
         if shading != "torch":
@@ -533,7 +565,7 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
             raise NotImplementedError("orthographic projection is forward only")
     if shading == "torch":
         # the torch backend's semantics
-        shade = ("torch", bool(params.get("double_sided", False)), bool(params.get("use_quartic", False)))
+        shade = ("torch", bool(params.get("double_sided", False)), bool(params.get("use_quartic", False)), shadow)
         if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
             # differentiable call (no normal / pos outputs on this path)
             image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, shade, *inputs)
@@ -546,11 +578,14 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
                                                double_sided=params.get("double_sided", False),
                                                use_quartic=params.get("use_quartic", False), aux=(normal, pos),
                                                waves_per_tile=params.get("waves_per_tile", 0))
+        extra = {}
+        if shadow:
+            extra["light_visibility"] = shadow_pass(buf, cam, rows, image, depth, nearest, shade[1], shade[2])
         return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64),
-                            normal=normal, pos=pos)
+                            normal=normal, pos=pos, **extra)
     if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
         # differentiable call: image and depth carry a grad_fn backed by the analytic HIP backward
-        image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, ("numpy", False, False), *inputs)
+        image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, ("numpy", False, False, False), *inputs)
     else:
         image, depth, nearest = render_buffers(buf, cam, rows=rows, mode=mode,
                                                waves_per_tile=params.get("waves_per_tile", 0))

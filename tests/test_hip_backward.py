@@ -188,3 +188,27 @@ def test_torch_shading_backward_matches_gradient_oracle(name):
         np.testing.assert_allclose(got, w, atol=2e-4 * scale + 1e-6, err_msg=key)
         checked += 1
     assert checked >= 9
+
+
+def test_torch_shading_backward_with_shadows():
+    """shadow=True under autograd: visibility is a constant 0 / 1 factor per light (the reference computes it with
+    comparisons), so the backward is the Phong backward with that factor -- against the gradient oracle fed the same
+    visibility."""
+    from oracle import np_oracle_tch
+    from surf_renderer_amd import render
+    scene, kw = _torch_shading_scene("g10_torch_autograd_phong")
+    ref = np_oracle_tch.render(scene, shadow=True, **kw)
+    H, W = ref["depth"].shape
+    rng = np.random.RandomState(9)
+    g_img = rng.uniform(-1, 1, size=(H, W, 3))
+    leaf_scene, leaves = _leaf_scene_tch(scene)
+    res = render(leaf_scene, device="cuda:0", shading="torch", shadow=True, **kw)
+    torch.sum(res["image"] * torch.as_tensor(g_img, dtype=torch.float32, device="cuda:0")).backward()
+    want = torch_oracle.gradients_tch(scene, g_img, None, ref=ref, visibility=ref["visibility"], **kw)
+    plain = torch_oracle.gradients_tch(scene, g_img, None, ref=ref, **kw)
+    assert np.abs(want["materials.albedo"] - plain["materials.albedo"]).max() > 1e-3    # shadows matter here
+    for key, t in leaves.items():
+        got = t.grad.cpu().numpy().astype(np.float64) if t.grad is not None else np.zeros(tuple(t.shape))
+        w = want[key].reshape(got.shape)
+        # a handful of grazing shadow rays may be decided differently: 0.5 % of the largest entry
+        np.testing.assert_allclose(got, w, atol=5e-3 * max(np.abs(w).max(), 1e-9) + 1e-6, err_msg=key)

@@ -45,3 +45,33 @@ def test_tch_oracle_matches_reference_torch_backend(case):
     scene, want, kw = load_tch_case(case)
     got = np_oracle_tch.render(scene, **kw)
     assert_tch_parity(got, want, scene["camera"]["far"])
+
+
+def test_shadow_rays_against_geometry():
+    """The shadow part of the oracle cannot be pinned by the reference (its shadow code needs CUDA tensors), so it is
+    checked against geometry: a unit disc at height 1 under a light at height 5 shadows the floor inside radius
+    5 / 4, and nothing else; the disc itself and the unshadowed floor see the light."""
+    f = lambda a: np.asarray(a, dtype=np.float64)
+    scene = {
+        "camera": {"viewport": [0, 0, 64, 48], "fovy": float(np.deg2rad(50.0)), "focal_length": 1.0,
+                   "eye": f([0.0, -9.0, 6.0, 1.0]), "at": f([0.0, 0.0, 0.0, 1.0]), "up": f([0.0, 0.0, 1.0, 0.0]),
+                   "near": 0.1, "far": 100.0},
+        "lights": {"pos": f([[0, 0, 5, 1]]), "color_idx": np.array([1]), "attenuation": f([[1, 0, 0]]), "ambient": f([0, 0, 0])},
+        "colors": f([[0, 0, 0], [1, 1, 1]]),
+        "materials": {"albedo": f([[0.8, 0.8, 0.8]]), "coeffs": f([[1, 0, 0]])},
+        "objects": {"plane": {"pos": f([[0, 0, 0, 1]]), "normal": f([[0, 0, 1, 0]]), "material_idx": np.array([0])},
+                    "disk": {"pos": f([[0, 0, 1, 1]]), "normal": f([[0, 0, 1, 0]]), "radius": f([1.0]), "material_idx": np.array([0])}},
+    }
+    res = np_oracle_tch.render(scene, shadow=True)
+    plain = np_oracle_tch.render(scene)
+    vis = res["visibility"][0]
+    pos, near = res["pos"], res["nearest"]
+    hit = res["depth"] <= 100.0
+    floor = hit & (near == 0)
+    rad = np.hypot(pos[..., 0], pos[..., 1])
+    assert (floor & (rad < 1.2)).sum() > 5 and (floor & (rad > 1.3)).sum() > 100
+    assert not vis[floor & (rad < 1.2)].any()                  # inside the shadow
+    assert vis[floor & (rad > 1.3)].all()                      # outside it
+    assert vis[hit & (near == 1)].all()                        # the disc does not shadow itself
+    assert np.all(res["image"][floor & (rad < 1.2)] == 0) and np.all(plain["image"][floor & (rad < 1.2)] > 0)
+    np.testing.assert_array_equal(res["image"][vis & hit], plain["image"][vis & hit])
