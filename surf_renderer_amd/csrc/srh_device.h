@@ -273,6 +273,23 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
   return y;
 }
 
+// 1/x for x != 0 without the IEEE division expansion: v_rcp_f64 seed and one Newton step (about 50 bits).  Fragment
+// stage only.
+__device__ __forceinline__ double rcp_newton(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
+// base ** expo for the specular lobe (base in [0, 1] after the relu, expo a material constant), in fp32 the way
+// tonemap_f32 does it: hardware log2 / exp2 while |expo * log2 base| <= 12 (error <= 1.1e-6 relative, and the lobe is
+// one term of a sum), library powf otherwise -- which also supplies 0 ** 0 = 1 and the other special values.
+__device__ __forceinline__ double spec_pow_f32(double base, double expo) {
+  const float x = (float)base, g = (float)expo;
+  const float y = g * __builtin_amdgcn_logf(x);
+  const bool direct = (x >= 1e-30f && x <= 1e30f && fabsf(y) <= 12.0f) || (x == 0.0f && g > 0.0f);
+  return (double)(direct ? __builtin_amdgcn_exp2f(y) : powf(x, g));
+}
+
 // image ** gamma of the tonemap (numpy/renderer.py:140-142) evaluated in fp32: x is already within half an
 // fp32 ulp of the reference value.  x^g = exp2(g * log2 x) on the hardware v_log_f32 / v_exp_f32 (1 ulp each):
 // the error of y = g log2 x is at most 2^-23 |y|, so with |y| <= 12 the result is off by at most
@@ -365,21 +382,22 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
       const float* lp = F.lpos + 4 * l;
       const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
       const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-      const double dist = sqrt(len2);
-      const double inv = (dist > 0.0) ? 1.0 / dist : 1.0;
+      // |l| and 1 / |l| from one reciprocal square root (equal to ~1e-15, immaterial after the fp32 store)
+      const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;
+      const double dist = (len2 > 0.0) ? len2 * inv : 0.0;
       const double lh[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
       const double kc = F.latt ? (double)F.latt[3 * l] : 1.0, kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0,
                    kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
       const double dp = F.use_quartic ? (len2 * len2) : len2;
       const double den = (kc + dist * kl) + dp * kq;
-      const double afac = 1.0 / ((fabs(den) > 0.0) ? den : 1.0);
+      const double afac = (fabs(den) > 0.0) ? rcp_newton(den) : 1.0;
       const double ldn = (lh[0] * n[0] + lh[1] * n[1]) + lh[2] * n[2];
       double ndotl = sgn * (afac * ldn);
       // reflect_ray(-l^, n) = 2 (l^.n) n - l^ ;  dotted with the view direction
       double rdotc = sgn * (2.0 * ldn * cdotn - ((cdir[0] * lh[0] + cdir[1] * lh[1]) + cdir[2] * lh[2]));
       ndotl = fmax(ndotl, 0.0);
       rdotc = fmax(rdotc, 0.0);
-      const double spec = (cf[1] != 0.0) ? cf[1] * pow(rdotc, cf[2]) : 0.0;
+      const double spec = (cf[1] != 0.0) ? cf[1] * spec_pow_f32(rdotc, cf[2]) : 0.0;
       // light visibility (shadow rays, :116-118) multiplies light colour x albedo, not the ambient term
       const double w = (cf[0] * ndotl + spec) * (double)((vis >> l) & 1ull);
       const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
