@@ -50,6 +50,11 @@ def main(argv=None) -> int:
     ap.add_argument("--width", type=int)
     ap.add_argument("--height", type=int)
     ap.add_argument("--mode", default="auto", help="hip only: auto | exact | fast | binned")
+    ap.add_argument("--shading", default="numpy", choices=["numpy", "torch"],
+                    help="hip only: which reference backend's semantics to follow (torch: Phong model with "
+                         "attenuation / specular / ambient, orthographic cameras, shadows)")
+    ap.add_argument("--double_sided", action="store_true", help="hip, torch shading: flip normals towards the viewer")
+    ap.add_argument("--shadow", action="store_true", help="hip, torch shading: shadow rays (all pairs)")
     args = ap.parse_args(argv)
 
     from .scene import load_scene, scene_to_numpy
@@ -61,7 +66,10 @@ def main(argv=None) -> int:
         print(f"backend {args.use!r} is not importable here: {exc}", file=sys.stderr)
         return 2
     if args.use == "hip":
-        res = backend.render(scene, mode=args.mode)
+        kw = {}
+        if args.shading == "torch":
+            kw = {"shading": "torch", "double_sided": args.double_sided, "shadow": args.shadow}
+        res = backend.render(scene, mode=args.mode, **kw)
     elif args.use == "np":
         res = backend.render(scene_to_numpy(scene))
     else:
