@@ -147,6 +147,27 @@ def main():
     scratch = [buf.new_workspace(W, H) for _ in range(n_str)]
     equal_slabs = H % world == 0
     batched = use_dist and equal_slabs and args.gather == "alltoall" and not frames_par
+    if batched:
+        # pre-flight: one tiny exchange; if this stack cannot do it, every rank falls back to the gather to rank 0
+        ok = torch.ones(1, device=device)
+        try:
+            probe = torch.arange(world * 4, dtype=torch.float32, device=device).reshape(world, 1, 4) + 100.0 * rank
+            got = torch.empty_like(probe)
+            exchange_frames(probe, got)
+            torch.cuda.synchronize(device)
+            want = torch.stack([torch.arange(4, dtype=torch.float32, device=device) + 4 * rank + 100.0 * g
+                                for g in range(world)]).reshape(world, 1, 4)
+            if not torch.equal(got, want):
+                ok.zero_()
+        except Exception as exc:                          # noqa: BLE001 -- any failure means "do not use it"
+            print(f"[bench] rank {rank}: all-to-all pre-flight failed ({exc!r})", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if rank == 0:
+                print("[bench] all-to-all collection unavailable: falling back to one gather per frame to rank 0",
+                      file=sys.stderr)
+            batched = False
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
