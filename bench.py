@@ -33,11 +33,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # med3, bfi, packed f32, fp64), which a SIMD issues at one wave-instruction per 4 cycles whatever the number of
 # waves (tools/ubench_valu.hip: 1.75-1.85 ns; only plain add/mul/logic reach 2 cycles): 1024 SIMDs x 2.4 GHz / 4.
 VALU_PEAK_GINSTR_S = 614.4
-# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_d_pmc_counters.txt)
-VALU_WAVE_INSTR_PER_LAUNCH = 50.9e6
-# HBM bytes of one render launch of the default workload from the PMC counters (same file): WRITE_SIZE 70 999 KiB +
-# FETCH_SIZE 17 993 KiB x 2 (the guide's gfx950 correction for the read side, worst case)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (70999 + 2 * 17993) * 1024.0
+# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_e_pmc_counters.txt)
+VALU_WAVE_INSTR_PER_LAUNCH = 49.9e6
+# HBM bytes of one render launch of the default workload from the PMC counters (same file): WRITE_SIZE 70 995 KiB +
+# FETCH_SIZE 18 025 KiB x 2 (the guide's gfx950 correction for the read side, worst case)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = (70995 + 2 * 18025) * 1024.0
 
 
 def parse():
@@ -362,13 +362,18 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None,
-                         "traffic_source": "profiles/r01_d_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                         "traffic_source": "profiles/r01_e_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes), constant" if default_workload else None,
                          "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes,
+                         # `kernel_ms` is one launch's duration WHILE `concurrent_launches` frames share the GPU (their
+                         # render kernels overlap); per unit of job time the kernel moves alg_bytes every ms_per_step
+                         "concurrent_launches": n_str,
+                         "achieved_per_job_time": alg_bytes / (elapsed / args.steps) / 1e9,
                          "note": "the kernel is bound by vector-instruction issue, not by HBM; see valu_issue"},
             "valu_issue": ({"achieved": ginstr_s, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
                             "frac": ginstr_s / VALU_PEAK_GINSTR_S,
+                            "frac_per_job_time": VALU_WAVE_INSTR_PER_LAUNCH / (elapsed / args.steps) / 1e9 / VALU_PEAK_GINSTR_S,
                             "wave_instr_per_launch": VALU_WAVE_INSTR_PER_LAUNCH,
                             "source": "SQ_INSTS_VALU (profiles/) over the live kernel time; peak = one VOP3-class "
                                       "instruction per SIMD per 4 cycles"} if default_workload else None),
