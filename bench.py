@@ -29,6 +29,10 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic flops of one ray-disc test (arithmetic only, per-primitive constants hoisted) and the
+# fp32 vector peak it prices them against
+FLOP_PER_DISK_TEST = 17
+VALU_F32_PEAK_TFLOPS = 157.3
 # What actually bounds the render kernel is vector-instruction issue.  Its loops are VOP3-class instructions (fma,
 # med3, bfi, packed f32, fp64), which a SIMD issues at one wave-instruction per 4 cycles whatever the number of
 # waves (tools/ubench_valu.hip: 1.75-1.85 ns; only plain add/mul/logic reach 2 cycles): 1024 SIMDs x 2.4 GHz / 4.
@@ -371,6 +375,13 @@ def main():
                          "concurrent_launches": n_str,
                          "achieved_per_job_time": alg_bytes / (elapsed / args.steps) / 1e9,
                          "note": "the kernel is bound by vector-instruction issue, not by HBM; see valu_issue"},
+            # SURVEY 8d's figure: algorithmic flops of ALL (pixel, primitive) pairs per second against the fp32 vector
+            # peak.  All-pairs evaluation tops out at frac = 1 (about 22 frames/s); the binned kernel proves most pairs
+            # cannot matter and never evaluates them, hence a value far above 1.
+            "valu_algorithmic": {"achieved": fps * tests * FLOP_PER_DISK_TEST / 1e12, "peak": VALU_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s (algorithmic, all pairs)",
+                                 "frac": fps * tests * FLOP_PER_DISK_TEST / 1e12 / VALU_F32_PEAK_TFLOPS,
+                                 "flop_per_test": FLOP_PER_DISK_TEST},
             "valu_issue": ({"achieved": ginstr_s, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
                             "frac": ginstr_s / VALU_PEAK_GINSTR_S,
                             "frac_per_job_time": VALU_WAVE_INSTR_PER_LAUNCH / (elapsed / args.steps) / 1e9 / VALU_PEAK_GINSTR_S,
