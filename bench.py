@@ -78,13 +78,13 @@ def parse():
                     help="after the timed loop compare the last collected frame on this rank with a fresh eager render "
                          "of the same rows (stream / graph / collective ordering self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pixels", type=int, default=2048, help="pixels in the CPU-baseline sample")
+    ap.add_argument("--cpu-pixels", type=int, default=4096, help="pixels in the CPU-baseline sample (about 14 s of numpy)")
     return ap.parse_args()
 
 
 def cpu_baseline(scene, prims, width, height, npix):
     """The oracle (numpy restatement of the reference's CPU path) timed on this host, on a bounded
-    sample of the same workload: `npix` consecutive pixels from the middle image row against all
+    sample of the same workload: `npix` consecutive pixels (row-major) centred on the middle image row against all
     primitives.  numpy's elementwise kernels run on one core."""
     from oracle import np_oracle                       # checker / baseline only -- never the product path
     from surf_renderer_amd.scene import scene_to_numpy
@@ -99,7 +99,7 @@ def cpu_baseline(scene, prims, width, height, npix):
             "kind": "port", "mtests_per_s": tps / 1e6,
             "extrapolated_s_per_frame": float(prims) * width * height / tps,
             "host_cpus": os.cpu_count(),
-            "sample": f"{npix} consecutive pixels of the middle row x {prims} discs ({tests:.3g} tests, "
+            "sample": f"{npix} consecutive pixels around the middle of the image x {prims} discs ({tests:.3g} tests, "
                       f"{dt:.1f} s), oracle/np_oracle.py fp64, pixel tile 64; frames/s extrapolated"}
 
 
