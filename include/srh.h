@@ -195,7 +195,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
  * images (n_views,H,W,3), depths (n_views,H,W), nearests (n_views,H,W; may be NULL) are stacked.  Every kernel of the
  * frame pipeline is launched once for the whole batch (the view is a grid dimension), so small views cost neither
  * six launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
- * srh_workspace_bytes_views(...) bytes.  Not thread-safe (one pinned staging buffer per process). */
+ * srh_workspace_bytes_views(...) bytes.  Calls are serialised on one pinned staging buffer per process. */
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views);
 int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,

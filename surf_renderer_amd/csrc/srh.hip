@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "srh.h"
 #include "srh_device.h"
 #include "srh_reject.h"
@@ -779,6 +781,7 @@ size_t views_header_bytes(int n_views) { return align_up((size_t)n_views * sizeo
 FrameDev* g_stage = nullptr;          // pinned staging for the FrameDev array of the batch being submitted
 size_t g_stage_cap = 0;
 hipEvent_t g_stage_done = nullptr;    // the previous batch's upload from g_stage has finished
+std::mutex g_stage_mu;                // one batch at a time fills and submits the staging buffer
 }  // namespace
 
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views) {
@@ -809,6 +812,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     return fail(SRH_E_RANGE, "workspace holds %zu bytes, %d views need %zu", workspace_bytes, n_views,
                 head + (size_t)n_views * one);
   hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_stage_mu);
   // pinned staging, reused from batch to batch once the previous upload has left it
   if (!g_stage_done) {
     const hipError_t ee = hipEventCreateWithFlags(&g_stage_done, hipEventDisableTiming);
