@@ -47,8 +47,8 @@ PMC_TRAFFIC_BYTES_PER_LAUNCH = (70995 + 2 * 18025) * 1024.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--mode", default="auto", choices=["auto", "exact", "fast", "binned"])
     ap.add_argument("--prims", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=2048)
