@@ -125,7 +125,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from surf_renderer_amd import _lib, renderer, synthetic
-    from surf_renderer_amd.dist import exchange_frames, gather_rows, row_slab
+    from surf_renderer_amd.dist import FrameBatcher, exchange_frames, gather_rows, row_slab
 
     W, H, M = args.width, args.height, args.prims
     scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
@@ -220,37 +220,30 @@ def main():
 
     if batched:
         n_bat = 2
-        send = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
-        recv = [torch.empty((world, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_bat)]
-        pending = [None] * n_bat
-        def exchange(b):
+
+        def render_slot(i, slot, ev):
+            k = i % world
+            enqueue((i // world % n_bat, k), streams[k % n_str], *views(slot), scratch[k % n_str], ev)
+
+        def before_exchange():
             for s_ in streams:
                 main.wait_stream(s_)               # every slab of the batch is rendered
-            pending[b] = exchange_frames(send[b], recv[b], async_op=True)
+
+        def after_reuse_wait():
+            for s_ in streams:
+                s_.wait_stream(main)               # main waited for the exchange that used this buffer
+
+        batcher = FrameBatcher(world, (h, 4 * W), torch.float32, device, render_slot, before_exchange,
+                               after_reuse_wait, n_batches=n_bat)
+        send, recv = batcher.send, batcher.recv
 
         def step(ev=None):
-            i = counter[0]
-            counter[0] += 1
-            b, k = (i // world) % n_bat, i % world
-            if k == 0 and pending[b] is not None:
-                pending[b].wait()                  # main stream: this buffer's previous batch has left
-                pending[b] = None
-                for s_ in streams:
-                    s_.wait_stream(main)
-            image, depth = views(send[b][k])
-            enqueue((b, k), streams[k % n_str], image, depth, scratch[k % n_str], ev)
-            if k == world - 1:
-                exchange(b)
+            batcher.submit(ev)
+            counter[0] = batcher.count
 
         def fence():
-            i = counter[0]
-            if i % world:                          # deliver the unfinished batch too (its empty slots travel as they are)
-                exchange((i // world) % n_bat)
-                counter[0] = (i // world + 1) * world
-            for b in range(n_bat):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+            batcher.flush()
+            counter[0] = batcher.count
             torch.cuda.synchronize(device)
             dist.barrier()
             torch.cuda.synchronize(device)
@@ -319,7 +312,9 @@ def main():
         renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(*views(ref), None))
         torch.cuda.synchronize(device)
         if batched:                                    # my own slab inside the frames assembled on this rank
-            got = [recv[b][rank] for b in range(n_bat) if counter[0] > b * world]
+            rendered = args.warmup + args.steps        # frames really rendered (a partial last batch has empty slots)
+            got = [recv[b][rank] for b in range(n_bat)
+                   if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
         else:
             got = [slabs[b] for b in range(min(n_buf, counter[0]))]
         for t in got:

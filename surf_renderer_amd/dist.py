@@ -110,3 +110,63 @@ def exchange_frames(send: torch.Tensor, recv: torch.Tensor, group: Optional[dist
     if not async_op:
         handle.wait()
     return handle
+
+
+class FrameBatcher:
+    """Scheduling of the batched collection: frames are rendered into `send[b][k]` (b = batch buffer, k = frame within
+    the batch of P = world frames), a full batch is exchanged (`exchange_frames`) so that frame k lands on rank k, and a
+    batch buffer is reused only after its exchange has completed.  Stream handling is the caller's, through three
+    hooks, so the same schedule runs on HIP streams (bench.py) and on CPU tensors under gloo (the tests):
+
+        render(i, slot)          fill `slot` ((h, ...) view of the send buffer) with this rank's slab of frame i
+        before_exchange()        make the exchange wait for every render issued so far
+        after_reuse_wait()       make later renders wait until the exchange that just completed has released a buffer
+
+    `frame(b)` is the receive buffer of batch buffer b: on rank k it holds frame (batch * P + k), slab g at [g]."""
+
+    def __init__(self, world: int, slab_shape, dtype, device, render, before_exchange=None, after_reuse_wait=None,
+                 n_batches: int = 2, group: Optional[dist.ProcessGroup] = None):
+        self.world, self.group, self.n_batches = world, group, n_batches
+        self.send = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
+        self.recv = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
+        self.pending: List[Optional[GatherHandle]] = [None] * n_batches
+        self.delivered: List[int] = [-1] * n_batches          # index of the batch each receive buffer holds
+        self._render, self._before, self._after = render, before_exchange, after_reuse_wait
+        self.count = 0
+
+    def slot(self, i: int) -> Tuple[int, int]:
+        return (i // self.world) % self.n_batches, i % self.world
+
+    def submit(self, *render_args) -> None:
+        """Render the next frame; exchange its batch when it is the last of it."""
+        i = self.count
+        self.count += 1
+        b, k = self.slot(i)
+        if k == 0 and self.pending[b] is not None:
+            self.pending[b].wait()                    # this buffer's previous batch has left
+            self.pending[b] = None
+            if self._after:
+                self._after()
+        self._render(i, self.send[b][k], *render_args)
+        if k == self.world - 1:
+            self._exchange(b, i // self.world)
+
+    def _exchange(self, b: int, batch_index: int) -> None:
+        if self._before:
+            self._before()
+        self.pending[b] = exchange_frames(self.send[b], self.recv[b], group=self.group, async_op=True)
+        self.delivered[b] = batch_index
+
+    def flush(self) -> None:
+        """Deliver an unfinished batch too (its unrendered slots travel as they are) and wait for everything."""
+        i = self.count
+        if i % self.world:
+            self._exchange((i // self.world) % self.n_batches, i // self.world)
+            self.count = (i // self.world + 1) * self.world
+        for b in range(self.n_batches):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def frame(self, b: int) -> torch.Tensor:
+        return self.recv[b]

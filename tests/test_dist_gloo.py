@@ -119,3 +119,53 @@ def test_batched_frame_exchange_puts_frame_k_on_rank_k(world):
         assert p.exitcode == 0
     got = [q.get(timeout=5) for _ in range(2 * world)]
     assert all(ok for _, ok in got), got
+
+
+def _batcher_worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from surf_renderer_amd.dist import FrameBatcher
+        h, w = 2, 3
+
+        def render(i, slot):
+            slot.fill_(1000.0 * i + rank)              # "slab of rank `rank` for frame i"
+
+        fb = FrameBatcher(world, (h, w), torch.float32, "cpu", render)
+        ok = True
+        for i in range(n_frames):
+            # a batch buffer about to be refilled must hold what was delivered into it: check before it is reused
+            fb.submit()
+        fb.flush()
+        # after the flush every receive buffer holds the last batch delivered into it
+        for b in range(fb.n_batches):
+            batch = fb.delivered[b]
+            if batch < 0:
+                continue
+            frame = batch * world + rank               # the frame this rank assembled in that batch
+            for g in range(world):
+                want = 1000.0 * frame + g
+                rendered = frame < n_frames            # slots of a partial last batch were never rendered
+                if rendered and not bool(torch.all(fb.frame(b)[g] == want)):
+                    ok = False
+        q.put((rank, ok, fb.count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (3, 7), (2, 5)])
+def test_frame_batcher_schedule(world, n_frames):
+    """The batched collection's schedule (bench.py runs it on HIP streams): frame k of a batch ends up complete on
+    rank k, batch buffers are reused only after their exchange, and a partial last batch is delivered on flush."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batcher_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = [q.get(timeout=5) for _ in range(world)]
+    assert all(ok for _, ok, _ in got), got
+    assert all(count == -(-n_frames // world) * world for _, _, count in got)
