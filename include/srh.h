@@ -191,8 +191,10 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
 
 /* Many views of one scene in one call: the batch axis of the reference's real callers, which render one view per
  * render() call in a Python loop (diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  `cameras` is an
- * array of n_views cameras with one viewport size; `params` is shared (whole frames, binned mode, dense outputs);
- * images (n_views,H,W,3), depths (n_views,H,W), nearests (n_views,H,W; may be NULL) are stacked.  Every kernel of the
+ * array of n_views cameras with one viewport size; `params` is shared (binned mode; row range and output row strides as
+ * in srh_render_fwd, so a multi-GPU rank can render its slab of a whole batch of frames); the outputs are stacked:
+ * view v starts v * rows * row_stride elements after view 0 in images (n_views,rows,W,3), depths (n_views,rows,W)
+ * and nearests (may be NULL).  Every kernel of the
  * frame pipeline is launched once for the whole batch (the view is a grid dimension), so small views cost neither
  * six launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
  * srh_workspace_bytes_views(...) bytes.  Calls are serialised on one pinned staging buffer per process. */

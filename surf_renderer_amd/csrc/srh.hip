@@ -834,7 +834,6 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     FrameDev& F = g_stage[v];
     int rc = setup_frame(&cameras[v], objects, lights, materials, params, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
-    if (F.row0 != 0 || F.row1 != F.H) return fail(SRH_E_RANGE, "srh_render_views renders whole frames (rows 0..H)");
     if (F.ortho) return fail(SRH_E_CAMERA, "srh_render_views: perspective cameras only");
     setup_binning(F, L, ws + head + (size_t)v * one);
   }

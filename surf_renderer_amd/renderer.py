@@ -441,6 +441,39 @@ class _RenderFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads.get(k) for k in keys)
 
 
+def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], images: torch.Tensor, depths: torch.Tensor,
+                         nearests: Optional[torch.Tensor] = None, rows: Optional[Tuple[int, int]] = None,
+                         workspace: Optional[torch.Tensor] = None, image_row_stride: int = 0,
+                         depth_row_stride: int = 0, **shading_kw) -> torch.Tensor:
+    """Low-level form of ``render_views``: resident scene buffers, camera structs, caller-provided stacked outputs
+    (view v starts v * rows * row_stride elements after view 0) and an optional row slab.  One library call, every
+    pipeline kernel launched once for the whole batch.  Returns the workspace (pass it back in to reuse it)."""
+    lib = _lib.load()
+    width, height = frame_size(cams[0])
+    r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
+    n = len(cams)
+    shading = shading_kw.get("shading", "numpy")
+    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES["auto"],
+                            tonemap_gamma=0 if buf.gamma is None else 1,
+                            gamma=1.0 if buf.gamma is None else buf.gamma,
+                            shading=_lib.SHADING[shading], double_sided=int(bool(shading_kw.get("double_sided", False))),
+                            use_quartic=int(bool(shading_kw.get("use_quartic", False))),
+                            waves_per_tile=int(shading_kw.get("waves_per_tile", 0)),
+                            image_row_stride=int(image_row_stride), depth_row_stride=int(depth_row_stride))
+    nbytes = lib.srh_workspace_bytes_views(C.byref(buf.objects), width, height, n)
+    if nbytes == 0:
+        raise _lib.SrhError(-2, lib.srh_last_error().decode())
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=buf.device)
+    arr = (_lib.SrhCamera * n)(*cams)
+    with torch.cuda.device(buf.device):
+        _lib.check(lib.srh_render_views(n, arr, C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                        C.byref(params), workspace.data_ptr(), workspace.numel(), images.data_ptr(),
+                                        depths.data_ptr(), nearests.data_ptr() if nearests is not None else None,
+                                        _stream_ptr(buf.device)))
+    return workspace
+
+
 def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], device="cuda", mode: str = "auto",
                  streams: int = 4, want_nearest: bool = True, batch: int = 256, **shading_kw) -> Dict[str, torch.Tensor]:
     """Many cameras, one scene: the batch axis of the reference's real callers (one ``render()`` per view in a

@@ -282,3 +282,29 @@ def test_saturated_list_positions_are_bit_identical():
     scene = synthetic.disk_cloud_scene(6000, 64, 64, radius=0.9, seed=2)      # every disc covers most of the 16 tiles
     ref = _modes_identical(scene, modes=("exact", "binned"))
     assert np.isfinite(ref["depth"]).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_views_batch_of_row_slabs_into_interleaved_buffers():
+    """What a multi-GPU rank does per batch: its row slab of several frames, one library call, written into the
+    (frames, rows, 4W) send buffer of the collection ([W x rgb | W x depth] per row) -- equal to per-frame calls."""
+    from surf_renderer_amd import renderer, synthetic
+    scene = synthetic.disk_cloud_scene(4000, 320, 256, radius=0.05, seed=8)
+    buf = renderer.flatten_scene(scene, "cuda:0")
+    cams = []
+    for k in range(3):
+        cam = dict(scene["camera"])
+        cam["eye"] = [0.3 * k, -0.2 * k, 4.0, 1.0]
+        cams.append(renderer.camera_struct(cam))
+    W, r0, r1 = 320, 64, 160
+    h = r1 - r0
+    send = torch.zeros((3, h, 4 * W), dtype=torch.float32, device="cuda:0")
+    img = send.as_strided((3, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
+    dep = send.as_strided((3, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+    renderer.render_views_buffers(buf, cams, img, dep, rows=(r0, r1), image_row_stride=4 * W, depth_row_stride=4 * W)
+    torch.cuda.synchronize()
+    for k, cam in enumerate(cams):
+        i1, d1, _ = renderer.render_buffers(buf, cam, rows=(r0, r1))
+        np.testing.assert_array_equal(img[k].cpu().numpy(), i1.cpu().numpy())
+        np.testing.assert_array_equal(dep[k].cpu().numpy(), d1.cpu().numpy())
+    assert np.isfinite(dep.cpu().numpy()).mean() > 0.2
