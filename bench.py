@@ -71,6 +71,11 @@ def parse():
                     help="rows (the metric's definition): every frame is row-tiled over the ranks and collected.  "
                          "frames: every rank renders whole frames of its own, nothing is collected -- the axis the "
                          "reference's callers actually have (SURVEY 8f row f4); reported as weak scaling")
+    ap.add_argument("--batch-call", default="auto", choices=["auto", "on", "off"],
+                    help="multi-GPU batched collection: render a rank's slab of all P frames of a batch with ONE "
+                         "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
+                         "auto = on from 8 ranks (rehearsed with --as-rank: 41 vs 45+ us per frame at P = 8, but "
+                         "68 vs 57 at P = 4, where per-frame launches on three streams overlap better)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -176,7 +181,11 @@ def main():
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
     ev_every = 1 if args.graph == "off" else 8
-    events = [_lib.EventPair() if i % ev_every == 0 else None for i in range(args.steps)]
+    if batched and (args.batch_call == "on" or (args.batch_call == "auto" and world >= 8)):
+        # whole batches are one library call; every 8th batch is rendered frame by frame with the events
+        events = [_lib.EventPair() if (i // world) % 8 == 0 else None for i in range(args.steps)]
+    else:
+        events = [_lib.EventPair() if i % ev_every == 0 else None for i in range(args.steps)]
     counter = [0]
 
     graphs = {}
@@ -237,16 +246,73 @@ def main():
                                after_reuse_wait, n_batches=n_bat)
         send, recv = batcher.send, batcher.recv
 
+        # One library call per batch: the P frames of a batch are the "views" of srh_render_views, rendered straight
+        # into the send buffer -- 7 launches per batch instead of 7 per frame, which is what a rank's small slab needs
+        # (its kernels are short; per-frame launches leave the GPU idle between them).  Every `ev_every`-th batch is
+        # still rendered frame by frame with the timing events around the render kernel.
+        batch_call = args.batch_call == "on" or (args.batch_call == "auto" and world >= 8)
+        views_ws = [None] * n_bat
+        cams = [cam] * world
+
+        def render_batch(first, send_b):
+            st = streams[(first // world) % n_str]
+            b = (first // world) % n_bat
+            img = send_b.as_strided((world, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
+            dep = send_b.as_strided((world, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+            with torch.cuda.stream(st):
+                views_ws[b] = renderer.render_views_buffers(buf, cams, img, dep, rows=(r0, r1), workspace=views_ws[b],
+                                                            image_row_stride=4 * W, depth_row_stride=4 * W)
+
+        def step_batch(evs):
+            """Render and submit one whole batch; `evs` = per-frame event pairs (or Nones)."""
+            if not batch_call or any(e is not None for e in evs):
+                for e in evs:
+                    batcher.submit(e)
+            else:
+                batcher.submit_batch(render_batch)
+
+        pending_evs = []
+
         def step(ev=None):
-            batcher.submit(ev)
-            counter[0] = batcher.count
+            pending_evs.append(ev)
+            if len(pending_evs) == world:
+                step_batch(list(pending_evs))
+                pending_evs.clear()
+            counter[0] += 1
+
+        def drain_partial():
+            for e in pending_evs:                  # a partial last batch goes frame by frame
+                batcher.submit(e)
+            pending_evs.clear()
 
         def fence():
+            drain_partial()
             batcher.flush()
-            counter[0] = batcher.count
             torch.cuda.synchronize(device)
             dist.barrier()
             torch.cuda.synchronize(device)
+    elif args.as_rank and args.batch_call == "on":
+        # rehearsal of a rank's batched rendering on one GPU: its slab of P frames per library call, no collection
+        ep = int(args.as_rank.split("/")[1])
+        bufs = [torch.empty((ep, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_str)]
+        wss = [None] * n_str
+        acc = [0]
+
+        def step(ev=None):
+            acc[0] += 1
+            counter[0] += 1
+            if acc[0] % ep:
+                return
+            j = (acc[0] // ep) % n_str
+            img = bufs[j].as_strided((ep, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
+            dep = bufs[j].as_strided((ep, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+            with torch.cuda.stream(streams[j]):
+                wss[j] = renderer.render_views_buffers(buf, [cam] * ep, img, dep, rows=(r0, r1), workspace=wss[j],
+                                                       image_row_stride=4 * W, depth_row_stride=4 * W)
+
+        def fence():
+            torch.cuda.synchronize(device)
+        n_buf, slabs = 0, []
     else:
         n_buf = n_str
         frames, slabs = [], []
@@ -323,7 +389,8 @@ def main():
         if rank == 0:
             print(f"[bench] check ok: {len(got)} collected slab(s) equal the eager render", file=sys.stderr)
 
-    kernel_ms = float(np.mean([e.elapsed_ms() for e in events if e is not None]))
+    timed = [e for e in events if e is not None and (not args.as_rank or args.batch_call != "on")]
+    kernel_ms = float(np.mean([e.elapsed_ms() for e in timed])) if timed else 0.0
     for e in events:
         if e is not None:
             e.close()
@@ -334,10 +401,10 @@ def main():
         # algorithmic HBM bytes of one render launch on this rank: primitives read once in the
         # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
         alg_bytes = M * 40.0 + h * W * (12.0 + 4.0)
-        ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned") \
             and not args.as_rank
-        ginstr_s = VALU_WAVE_INSTR_PER_LAUNCH / (kernel_ms * 1e-3) / 1e9
+        ginstr_s = VALU_WAVE_INSTR_PER_LAUNCH / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "gtests_per_s": fps * tests / 1e9,
@@ -355,6 +422,9 @@ def main():
                                  else "eager",
                        "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
                                       else f"rehearsal of rank {args.as_rank}",
+                       "launches": ("one srh_render_views call per batch of frames"
+                                    if batched and (args.batch_call == "on" or (args.batch_call == "auto" and world >= 8))
+                                    else "per frame"),
                        "collection": "none" if (not use_dist or frames_par) else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},

@@ -151,6 +151,22 @@ class FrameBatcher:
         if k == self.world - 1:
             self._exchange(b, i // self.world)
 
+    def submit_batch(self, render_batch, *render_args) -> None:
+        """Render a whole batch at once -- ``render_batch(first_frame, send_buffer, *args)`` fills all P slots of the
+        (P, h, ...) send buffer, e.g. with one ``srh_render_views`` call -- and exchange it.  Only at a batch boundary."""
+        if self.count % self.world:
+            raise RuntimeError("submit_batch in the middle of a batch")
+        batch_index = self.count // self.world
+        b = batch_index % self.n_batches
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+            if self._after:
+                self._after()
+        render_batch(self.count, self.send[b], *render_args)
+        self.count += self.world
+        self._exchange(b, batch_index)
+
     def _exchange(self, b: int, batch_index: int) -> None:
         if self._before:
             self._before()

@@ -131,11 +131,21 @@ def _batcher_worker(rank, world, port, n_frames, q):
         def render(i, slot):
             slot.fill_(1000.0 * i + rank)              # "slab of rank `rank` for frame i"
 
+        def render_batch(first, send):
+            for k in range(world):
+                send[k].fill_(1000.0 * (first + k) + rank)
+
         fb = FrameBatcher(world, (h, w), torch.float32, "cpu", render)
         ok = True
-        for i in range(n_frames):
-            # a batch buffer about to be refilled must hold what was delivered into it: check before it is reused
-            fb.submit()
+        i = 0
+        while i < n_frames:
+            # whole batches alternately in one go (what one srh_render_views call does) and frame by frame
+            if i % world == 0 and n_frames - i >= world and (i // world) % 2 == 0:
+                fb.submit_batch(render_batch)
+                i += world
+            else:
+                fb.submit()
+                i += 1
         fb.flush()
         # after the flush every receive buffer holds the last batch delivered into it
         for b in range(fb.n_batches):
