@@ -778,17 +778,20 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
 // ---- many views of one scene per call ---------------------------------------------------------------------------
 namespace {
 size_t views_header_bytes(int n_views) { return align_up((size_t)n_views * sizeof(FrameDev)); }
-FrameDev* g_stage = nullptr;          // pinned staging for the FrameDev array of the batch being submitted
-size_t g_stage_cap = 0;
-hipEvent_t g_stage_done = nullptr;    // the previous batch's upload from g_stage has finished
-std::mutex g_stage_mu;                // one batch at a time fills and submits the staging buffer
+// Frame descriptors of the batches in flight: a ring of kViewRing slots, each a pinned host staging area, a range of
+// the device's constant-memory array g_view_frames (read by the render kernel) and an event that says "the batch
+// that used this slot has finished".  The other kernels read the copy at the head of the caller's workspace.
+FrameDev* g_stage[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
+hipEvent_t g_slot_done[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
+unsigned g_next_slot = 0;
+std::mutex g_stage_mu;                // one call at a time claims a slot and submits
 }  // namespace
 
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views) {
   const size_t one = srh_workspace_bytes(objects, width, height);
   if (!one) return 0;
-  if (n_views < 1 || n_views > 65535) {
-    fail(SRH_E_RANGE, "n_views = %d, expected 1..65535", n_views);
+  if (n_views < 1 || n_views > kMaxViewsPerCall) {
+    fail(SRH_E_RANGE, "n_views = %d, expected 1..%d per call", n_views, kMaxViewsPerCall);
     return 0;
   }
   return views_header_bytes(n_views) + (size_t)n_views * one;
@@ -799,7 +802,8 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
                      float* images, float* depths, int32_t* nearests, void* stream) {
   if (!cameras || !params || !workspace) return fail(SRH_E_NULL, "cameras / params / workspace is NULL");
   if (!images || !depths) return fail(SRH_E_NULL, "images / depths is NULL");
-  if (n_views < 1 || n_views > 65535) return fail(SRH_E_RANGE, "n_views = %d, expected 1..65535", n_views);
+  if (n_views < 1 || n_views > kMaxViewsPerCall)
+    return fail(SRH_E_RANGE, "n_views = %d, expected 1..%d per call", n_views, kMaxViewsPerCall);
   if (params->mode != SRH_MODE_AUTO && params->mode != SRH_MODE_BINNED)
     return fail(SRH_E_TYPE, "srh_render_views renders in the binned mode only");
   if (params->normal_out || params->pos_out || params->ev_start || params->ev_stop)
@@ -813,35 +817,36 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
                 head + (size_t)n_views * one);
   hipStream_t st = (hipStream_t)stream;
   std::lock_guard<std::mutex> lock(g_stage_mu);
-  // pinned staging, reused from batch to batch once the previous upload has left it
-  if (!g_stage_done) {
-    const hipError_t ee = hipEventCreateWithFlags(&g_stage_done, hipEventDisableTiming);
-    if (ee != hipSuccess) { g_stage_done = nullptr; return hip_fail(ee, "hipEventCreate"); }
-  }
-  if (g_stage_cap < (size_t)n_views) {
-    if (g_stage) { (void)hipEventSynchronize(g_stage_done); (void)hipHostFree(g_stage); g_stage = nullptr; g_stage_cap = 0; }
-    const hipError_t em = hipHostMalloc((void**)&g_stage, (size_t)n_views * sizeof(FrameDev), hipHostMallocDefault);
-    if (em != hipSuccess) { g_stage = nullptr; return hip_fail(em, "hipHostMalloc(frames)"); }
-    g_stage_cap = (size_t)n_views;
+  // claim the next ring slot; its previous batch must have finished (host wait only when kViewRing batches are behind)
+  const unsigned slot = g_next_slot++ % kViewRing;
+  if (!g_slot_done[slot]) {
+    const hipError_t ee = hipEventCreateWithFlags(&g_slot_done[slot], hipEventDisableTiming);
+    if (ee != hipSuccess) { g_slot_done[slot] = nullptr; return hip_fail(ee, "hipEventCreate"); }
+    const hipError_t em = hipHostMalloc((void**)&g_stage[slot], (size_t)kMaxViewsPerCall * sizeof(FrameDev), hipHostMallocDefault);
+    if (em != hipSuccess) { g_stage[slot] = nullptr; return hip_fail(em, "hipHostMalloc(frames)"); }
   } else {
-    (void)hipEventSynchronize(g_stage_done);
+    (void)hipEventSynchronize(g_slot_done[slot]);
   }
+  FrameDev* stage = g_stage[slot];
   char* ws = (char*)workspace;
   WsLayout L;
   for (int v = 0; v < n_views; ++v) {
     const int w = cameras[v].viewport[2] - cameras[v].viewport[0], h = cameras[v].viewport[3] - cameras[v].viewport[1];
     if (w != W || h != H) return fail(SRH_E_RANGE, "view %d is %d x %d, view 0 is %d x %d", v, w, h, W, H);
-    FrameDev& F = g_stage[v];
+    FrameDev& F = stage[v];
     int rc = setup_frame(&cameras[v], objects, lights, materials, params, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
     if (F.ortho) return fail(SRH_E_CAMERA, "srh_render_views: perspective cameras only");
     setup_binning(F, L, ws + head + (size_t)v * one);
   }
   const FrameDev* Fs = (const FrameDev*)ws;
-  hipError_t e = hipMemcpyAsync(ws, g_stage, (size_t)n_views * sizeof(FrameDev), hipMemcpyHostToDevice, st);
+  hipError_t e = hipMemcpyAsync(ws, stage, (size_t)n_views * sizeof(FrameDev), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(frames)");
-  (void)hipEventRecord(g_stage_done, st);
-  const FrameDev& F0 = g_stage[0];
+  const int base = (int)slot * kMaxViewsPerCall;
+  e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_view_frames), stage, (size_t)n_views * sizeof(FrameDev),
+                             (size_t)base * sizeof(FrameDev), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyToSymbolAsync(frames)");
+  const FrameDev& F0 = stage[0];
   const unsigned V = (unsigned)n_views;
   const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F0.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
@@ -855,12 +860,13 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4)
                          ? params->waves_per_tile == 4 : (size_t)F0.ntiles * V < (size_t)SRH_SPLIT_TILES;
   if (F0.shading) {
-    if (split) hipLaunchKernelGGL((k_render_binned_views<true, 4>), dim3(groups * 4, V), dim3(256), 0, st, Fs, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups, V), dim3(256), 0, st, Fs, images, depths, nearests);
+    if (split) hipLaunchKernelGGL((k_render_binned_views<true, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups, V), dim3(256), 0, st, base, images, depths, nearests);
   } else {
-    if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, Fs, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups, V), dim3(256), 0, st, Fs, images, depths, nearests);
+    if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups, V), dim3(256), 0, st, base, images, depths, nearests);
   }
+  (void)hipEventRecord(g_slot_done[slot], st);
   e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "views launch");
 }

@@ -699,8 +699,10 @@ __device__ __forceinline__ void wave_lds_fence() {
 // keys are merged through LDS, and each wave finishes a quarter of the pixels.  Same arithmetic, a quarter of the
 // latency per tile and four times the waves: for frames (or row slabs of a multi-GPU job) with too few tiles to
 // fill 1024 SIMDs several times over.
+// F is restrict-qualified: in the many-views kernels it refers to device memory, and without the promise that no store
+// of this function touches it every store would force the frame constants to be read again
 template <bool TCH, int WPT>
-__device__ __forceinline__ void render_binned_body(const FrameDev& F, float* __restrict__ image,
+__device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ F, float* __restrict__ image,
                                                    float* __restrict__ depth, int32_t* __restrict__ nearest) {
   __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
   __shared__ int32_t front[4][4][64];         // global index of each pixel's front candidate (-1: none / saturated)
@@ -951,11 +953,18 @@ __global__ __launch_bounds__(256) void k_bin_count_views(const FrameDev* __restr
 __global__ __launch_bounds__(1024) void k_bin_scan_views(const FrameDev* __restrict__ Fs) { bin_scan_body(Fs[blockIdx.y]); }
 __global__ __launch_bounds__(256) void k_bin_fill_views(const FrameDev* __restrict__ Fs) { bin_fill_body(Fs[blockIdx.y]); }
 
+// The render kernel reads its view's frame constants from CONSTANT memory: loads from there are invariant, so hipcc
+// re-materialises them where they are used (as it does with a by-value kernel argument) instead of keeping 140 SGPRs
+// alive -- and spilling them -- across the whole kernel, which is what a plain device pointer costs (141 vs 114 us per
+// frame at config 5).
+constexpr int kMaxViewsPerCall = 256;
+constexpr int kViewRing = 4;                       // batches in flight before the host has to wait
+__constant__ FrameDev g_view_frames[kViewRing * kMaxViewsPerCall];
+
 template <bool TCH, int WPT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned_views(
-    const FrameDev* __restrict__ Fs, float* __restrict__ image, float* __restrict__ depth,
-    int32_t* __restrict__ nearest) {
-  const FrameDev& F = Fs[blockIdx.y];
+    int base, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  const FrameDev& F = g_view_frames[base + blockIdx.y];
   const size_t rows = (size_t)(F.row1 - F.row0), v = blockIdx.y;
   render_binned_body<TCH, WPT>(F, image + v * rows * F.img_stride, depth + v * rows * F.depth_stride,
                                nearest ? nearest + v * rows * F.near_stride : nullptr);
