@@ -74,8 +74,8 @@ def parse():
     ap.add_argument("--batch-call", default="auto", choices=["auto", "on", "off"],
                     help="multi-GPU batched collection: render a rank's slab of all P frames of a batch with ONE "
                          "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
-                         "auto = on from 8 ranks (rehearsed with --as-rank: 41 vs 45+ us per frame at P = 8, but "
-                         "68 vs 57 at P = 4, where per-frame launches on three streams overlap better)")
+                         "auto = on (rehearsed with --as-rank against per-frame graph replays, which multi-GPU runs "
+                         "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -181,7 +181,7 @@ def main():
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
     ev_every = 1 if args.graph == "off" else 8
-    if batched and (args.batch_call == "on" or (args.batch_call == "auto" and world >= 8)):
+    if batched and args.batch_call != "off":
         # whole batches are one library call; every 8th batch is rendered frame by frame with the events
         events = [_lib.EventPair() if (i // world) % 8 == 0 else None for i in range(args.steps)]
     else:
@@ -250,7 +250,7 @@ def main():
         # into the send buffer -- 7 launches per batch instead of 7 per frame, which is what a rank's small slab needs
         # (its kernels are short; per-frame launches leave the GPU idle between them).  Every `ev_every`-th batch is
         # still rendered frame by frame with the timing events around the render kernel.
-        batch_call = args.batch_call == "on" or (args.batch_call == "auto" and world >= 8)
+        batch_call = args.batch_call != "off"
         views_ws = [None] * n_bat
         cams = [cam] * world
 
@@ -423,8 +423,7 @@ def main():
                        "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
-                                    if batched and (args.batch_call == "on" or (args.batch_call == "auto" and world >= 8))
-                                    else "per frame"),
+                                    if batched and args.batch_call != "off" else "per frame"),
                        "collection": "none" if (not use_dist or frames_par) else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},
