@@ -76,6 +76,10 @@ def parse():
                          "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
                          "auto = on (rehearsed with --as-rank against per-frame graph replays, which multi-GPU runs "
                          "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
+    ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced"],
+                    help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
+                         "g and 2P-1-g of 2P, so that a scene that is densest in the middle loads every rank alike; "
+                         "auto = balanced where possible")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -130,7 +134,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from surf_renderer_amd import _lib, renderer, synthetic
-    from surf_renderer_amd.dist import FrameBatcher, exchange_frames, gather_rows, row_slab
+    from surf_renderer_amd.dist import FrameBatcher, balanced_slabs, exchange_frames, gather_rows, row_slab
 
     W, H, M = args.width, args.height, args.prims
     scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
@@ -177,6 +181,10 @@ def main():
                 print("[bench] all-to-all collection unavailable: falling back to one gather per frame to rank 0",
                       file=sys.stderr)
             batched = False
+    # the rows this rank renders: one slab, or two half-slabs (batched collection only; the collected frame is then the
+    # concatenation, in rank order, of [half-slab g | half-slab 2P-1-g])
+    balanced = batched and not args.as_rank and args.slabs != "contiguous" and H % (2 * world) == 0
+    pieces = balanced_slabs(H, rank, world) if balanced else [(r0, r1)]
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
@@ -194,7 +202,7 @@ def main():
     # ROCm 7.2, while the same schedule with eager launches runs clean; multi-GPU runs therefore launch eagerly.
     graph_state = {"on": args.graph == "on" or (args.graph == "auto" and not use_dist), "captured": 0}
 
-    def enqueue(key, stream, image, depth, ws, ev):
+    def enqueue(key, stream, image, depth, ws, ev, rows=None):
         """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,
         eager launches the first time, when a timing event pair is to be recorded, or when graphs are off."""
         if graph_state["on"] and ev is None:
@@ -204,8 +212,8 @@ def main():
                     g = torch.cuda.CUDAGraph()
                     # thread_local: the process group's watchdog thread may query events while we capture
                     with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
-                                                workspace=ws)
+                        renderer.render_buffers(buf, cam, rows=rows or (r0, r1), mode=args.mode,
+                                                out=(image, depth, None), workspace=ws)
                     graphs[key] = g
                     graph_state["captured"] += 1
                 except Exception as exc:                      # capture unsupported here: stay eager, say so
@@ -219,7 +227,7 @@ def main():
                     g.replay()
                 return
         with torch.cuda.stream(stream):
-            renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None),
+            renderer.render_buffers(buf, cam, rows=rows or (r0, r1), mode=args.mode, out=(image, depth, None),
                                     events=ev, workspace=ws)
 
     def views(slab):
@@ -232,7 +240,12 @@ def main():
 
         def render_slot(i, slot, ev):
             k = i % world
-            enqueue((i // world % n_bat, k), streams[k % n_str], *views(slot), scratch[k % n_str], ev)
+            at = 0
+            for j, (a, b_) in enumerate(pieces):   # the slot holds this rank's pieces one after the other
+                part = slot[at:at + (b_ - a)]
+                enqueue((i // world % n_bat, k, j), streams[k % n_str], *views(part), scratch[k % n_str],
+                        ev if j == 0 else None, rows=(a, b_))
+                at += b_ - a
 
         def before_exchange():
             for s_ in streams:
@@ -252,16 +265,20 @@ def main():
         # still rendered frame by frame with the timing events around the render kernel.
         batch_call = args.batch_call != "off"
         views_ws = [None] * n_bat
-        cams = [cam] * world
+        npc = len(pieces)                          # views per frame: the rank's pieces, all of ph rows
+        ph = pieces[0][1] - pieces[0][0]
+        cams = [cam] * (world * npc)
+        view_row0 = [a for _ in range(world) for a, _ in pieces]
 
         def render_batch(first, send_b):
             st = streams[(first // world) % n_str]
             b = (first // world) % n_bat
-            img = send_b.as_strided((world, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
-            dep = send_b.as_strided((world, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+            img = send_b.as_strided((world * npc, ph, W, 3), (ph * 4 * W, 4 * W, 3, 1), 0)
+            dep = send_b.as_strided((world * npc, ph, W), (ph * 4 * W, 4 * W, 1), 3 * W)
             with torch.cuda.stream(st):
-                views_ws[b] = renderer.render_views_buffers(buf, cams, img, dep, rows=(r0, r1), workspace=views_ws[b],
-                                                            image_row_stride=4 * W, depth_row_stride=4 * W)
+                views_ws[b] = renderer.render_views_buffers(buf, cams, img, dep, rows=(0, ph), view_row0=view_row0,
+                                                            workspace=views_ws[b], image_row_stride=4 * W,
+                                                            depth_row_stride=4 * W)
 
         def step_batch(evs):
             """Render and submit one whole batch; `evs` = per-frame event pairs (or Nones)."""
@@ -293,7 +310,10 @@ def main():
             torch.cuda.synchronize(device)
     elif args.as_rank and args.batch_call == "on":
         # rehearsal of a rank's batched rendering on one GPU: its slab of P frames per library call, no collection
-        ep = int(args.as_rank.split("/")[1])
+        er, ep = (int(t) for t in args.as_rank.split("/"))
+        rp = balanced_slabs(H, er, ep) if (args.slabs == "balanced" and H % (2 * ep) == 0) else [(r0, r1)]
+        npc_r, ph_r = len(rp), rp[0][1] - rp[0][0]
+        row0_r = [a for _ in range(ep) for a, _ in rp]
         bufs = [torch.empty((ep, h, 4 * W), dtype=torch.float32, device=device) for _ in range(n_str)]
         wss = [None] * n_str
         acc = [0]
@@ -304,10 +324,11 @@ def main():
             if acc[0] % ep:
                 return
             j = (acc[0] // ep) % n_str
-            img = bufs[j].as_strided((ep, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
-            dep = bufs[j].as_strided((ep, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+            img = bufs[j].as_strided((ep * npc_r, ph_r, W, 3), (ph_r * 4 * W, 4 * W, 3, 1), 0)
+            dep = bufs[j].as_strided((ep * npc_r, ph_r, W), (ph_r * 4 * W, 4 * W, 1), 3 * W)
             with torch.cuda.stream(streams[j]):
-                wss[j] = renderer.render_views_buffers(buf, [cam] * ep, img, dep, rows=(r0, r1), workspace=wss[j],
+                wss[j] = renderer.render_views_buffers(buf, [cam] * (ep * npc_r), img, dep, rows=(0, ph_r),
+                                                       view_row0=row0_r, workspace=wss[j],
                                                        image_row_stride=4 * W, depth_row_stride=4 * W)
 
         def fence():
@@ -355,7 +376,11 @@ def main():
         if batched:
             for b in range(n_bat):
                 for k in range(world):
-                    enqueue((b, k), streams[k % n_str], *views(send[b][k]), scratch[k % n_str], None)
+                    at = 0
+                    for j, (a, b_) in enumerate(pieces):
+                        enqueue((b, k, j), streams[k % n_str], *views(send[b][k][at:at + (b_ - a)]),
+                                scratch[k % n_str], None, rows=(a, b_))
+                        at += b_ - a
         else:
             for b in range(n_buf):
                 enqueue((b,), streams[b], *views(slabs[b]), scratch[b], None)
@@ -375,7 +400,10 @@ def main():
 
     if args.check:
         ref = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
-        renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(*views(ref), None))
+        at = 0
+        for a, b_ in pieces:
+            renderer.render_buffers(buf, cam, rows=(a, b_), mode=args.mode, out=(*views(ref[at:at + (b_ - a)]), None))
+            at += b_ - a
         torch.cuda.synchronize(device)
         if batched:                                    # my own slab inside the frames assembled on this rank
             rendered = args.warmup + args.steps        # frames really rendered (a partial last batch has empty slots)
@@ -400,7 +428,8 @@ def main():
         tests = float(M) * W * H
         # algorithmic HBM bytes of one render launch on this rank: primitives read once in the
         # reference's layout (pos 16 + normal 16 + radius 4 + material_idx 4 = 40 B) + rgb and depth written once
-        alg_bytes = M * 40.0 + h * W * (12.0 + 4.0)
+        timed_rows = pieces[0][1] - pieces[0][0]           # rows of the launch the event pairs bracket
+        alg_bytes = M * 40.0 + timed_rows * W * (12.0 + 4.0)
         ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned") \
             and not args.as_rank
@@ -424,6 +453,7 @@ def main():
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
                                     if batched and args.batch_call != "off" else "per frame"),
+                       "rows_per_rank": ("two half-slabs, g and 2P-1-g of 2P" if balanced else "one contiguous slab"),
                        "collection": "none" if (not use_dist or frames_par) else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 5
+#define SRH_ABI_VERSION 6
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -133,6 +133,8 @@ typedef struct SrhParams {
   void* ev_stop;                /* after the frame's dominant kernel (measurement hook); NULL = off */
   const void* visibility;       /* srh_render_bwd, SRH_SHADING_TORCH: the (rows,W) uint64 light-visibility bits that
                                    srh_shadow_shade wrote for this frame, or NULL (no shadows) */
+  const int32_t* view_row0;     /* srh_render_views only: HOST array of n_views first rows; view v renders rows
+                                   [view_row0[v], view_row0[v] + row1 - row0).  NULL = every view renders [row0, row1) */
 } SrhParams;
 
 int srh_abi_version(void);

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -54,7 +54,8 @@ class SrhParams(C.Structure):
                 ("normal_out", C.c_void_p), ("pos_out", C.c_void_p),
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("visibility", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("visibility", C.c_void_p),
+                ("view_row0", C.c_void_p)]
 
 
 class SrhGrads(C.Structure):

@@ -834,7 +834,12 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     const int w = cameras[v].viewport[2] - cameras[v].viewport[0], h = cameras[v].viewport[3] - cameras[v].viewport[1];
     if (w != W || h != H) return fail(SRH_E_RANGE, "view %d is %d x %d, view 0 is %d x %d", v, w, h, W, H);
     FrameDev& F = stage[v];
-    int rc = setup_frame(&cameras[v], objects, lights, materials, params, ws + head + (size_t)v * one, one, &F, &L);
+    SrhParams pv = *params;
+    if (params->view_row0) {                        // this view's own rows, same count for every view
+      pv.row0 = params->view_row0[v];
+      pv.row1 = pv.row0 + (params->row1 - params->row0);
+    }
+    int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
     if (F.ortho) return fail(SRH_E_CAMERA, "srh_render_views: perspective cameras only");
     setup_binning(F, L, ws + head + (size_t)v * one);

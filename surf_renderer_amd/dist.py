@@ -23,6 +23,18 @@ def row_slab(height: int, rank: int, world: int) -> Tuple[int, int]:
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
+def balanced_slabs(height: int, rank: int, world: int) -> List[Tuple[int, int]]:
+    """Two half-slabs per rank, g and 2P-1-g of 2P equal ones: an outer and an inner part of the image, so that a scene
+    that is densest in the middle loads every rank alike.  Needs height % (2 * world) == 0."""
+    if height % (2 * world):
+        raise ValueError(f"balanced slabs need height % {2 * world} == 0, got {height}")
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} of {world}")
+    hh = height // (2 * world)
+    a, b = rank, 2 * world - 1 - rank
+    return [(a * hh, (a + 1) * hh), (b * hh, (b + 1) * hh)]
+
+
 def all_slabs(height: int, world: int) -> List[Tuple[int, int]]:
     return [row_slab(height, g, world) for g in range(world)]
 

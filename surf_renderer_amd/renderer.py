@@ -444,10 +444,12 @@ class _RenderFunction(torch.autograd.Function):
 def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], images: torch.Tensor, depths: torch.Tensor,
                          nearests: Optional[torch.Tensor] = None, rows: Optional[Tuple[int, int]] = None,
                          workspace: Optional[torch.Tensor] = None, image_row_stride: int = 0,
-                         depth_row_stride: int = 0, **shading_kw) -> torch.Tensor:
+                         depth_row_stride: int = 0, view_row0: Optional[Sequence[int]] = None,
+                         **shading_kw) -> torch.Tensor:
     """Low-level form of ``render_views``: resident scene buffers, camera structs, caller-provided stacked outputs
-    (view v starts v * rows * row_stride elements after view 0) and an optional row slab.  One library call, every
-    pipeline kernel launched once for the whole batch.  Returns the workspace (pass it back in to reuse it)."""
+    (view v starts v * rows * row_stride elements after view 0) and an optional row slab; with ``view_row0`` view v
+    renders rows [view_row0[v], view_row0[v] + rows[1] - rows[0]) instead.  One library call, every pipeline kernel
+    launched once for the whole batch.  Returns the workspace (pass it back in to reuse it)."""
     lib = _lib.load()
     width, height = frame_size(cams[0])
     r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
@@ -460,6 +462,12 @@ def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], imag
                             use_quartic=int(bool(shading_kw.get("use_quartic", False))),
                             waves_per_tile=int(shading_kw.get("waves_per_tile", 0)),
                             image_row_stride=int(image_row_stride), depth_row_stride=int(depth_row_stride))
+    row0_arr = None
+    if view_row0 is not None:
+        if len(view_row0) != n:
+            raise ValueError("view_row0 needs one entry per view")
+        row0_arr = (C.c_int32 * n)(*[int(r) for r in view_row0])
+        params.view_row0 = C.cast(row0_arr, C.c_void_p)
     nbytes = lib.srh_workspace_bytes_views(C.byref(buf.objects), width, height, n)
     if nbytes == 0:
         raise _lib.SrhError(-2, lib.srh_last_error().decode())

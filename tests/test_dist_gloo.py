@@ -179,3 +179,16 @@ def test_frame_batcher_schedule(world, n_frames):
     got = [q.get(timeout=5) for _ in range(world)]
     assert all(ok for _, ok, _ in got), got
     assert all(count == -(-n_frames // world) * world for _, _, count in got)
+
+
+def test_balanced_slabs_partition_the_image():
+    from surf_renderer_amd.dist import balanced_slabs
+    for height, world in ((2048, 8), (2048, 2), (96, 3), (16, 1)):
+        rows = []
+        for g in range(world):
+            parts = balanced_slabs(height, g, world)
+            assert len(parts) == 2 and all(b - a == height // (2 * world) for a, b in parts)
+            rows += [r for a, b in parts for r in range(a, b)]
+        assert sorted(rows) == list(range(height))
+    with pytest.raises(ValueError):
+        balanced_slabs(100, 0, 8)

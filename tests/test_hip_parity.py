@@ -308,3 +308,16 @@ def test_views_batch_of_row_slabs_into_interleaved_buffers():
         np.testing.assert_array_equal(img[k].cpu().numpy(), i1.cpu().numpy())
         np.testing.assert_array_equal(dep[k].cpu().numpy(), d1.cpu().numpy())
     assert np.isfinite(dep.cpu().numpy()).mean() > 0.2
+    # views with their own first rows (a rank's two half-slabs of each frame of a batch)
+    hh = 48
+    row0 = [32, 176, 32, 176, 32, 176]
+    send2 = torch.zeros((6, hh, 4 * W), dtype=torch.float32, device="cuda:0")
+    img2 = send2.as_strided((6, hh, W, 3), (hh * 4 * W, 4 * W, 3, 1), 0)
+    dep2 = send2.as_strided((6, hh, W), (hh * 4 * W, 4 * W, 1), 3 * W)
+    renderer.render_views_buffers(buf, [c for c in cams for _ in range(2)], img2, dep2, rows=(0, hh), view_row0=row0,
+                                  image_row_stride=4 * W, depth_row_stride=4 * W)
+    torch.cuda.synchronize()
+    for v in range(6):
+        i1, d1, _ = renderer.render_buffers(buf, cams[v // 2], rows=(row0[v], row0[v] + hh))
+        np.testing.assert_array_equal(img2[v].cpu().numpy(), i1.cpu().numpy())
+        np.testing.assert_array_equal(dep2[v].cpu().numpy(), d1.cpu().numpy())
