@@ -78,8 +78,10 @@ def parse():
                          "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
     ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced"],
                     help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
-                         "g and 2P-1-g of 2P, so that a scene that is densest in the middle loads every rank alike; "
-                         "auto = balanced where possible")
+                         "g and P+g of 2P, so that a scene that is densest in the middle loads every rank alike.  "
+                         "auto = contiguous: rehearsed with --as-rank, the balanced form evens the ranks out (26-40 us "
+                         "instead of 9-34 us at P = 8) but its doubled per-view fixed work makes the slowest rank "
+                         "slower (40 vs 34 us at P = 8, 59 vs 56 at P = 4)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -182,8 +184,8 @@ def main():
                       file=sys.stderr)
             batched = False
     # the rows this rank renders: one slab, or two half-slabs (batched collection only; the collected frame is then the
-    # concatenation, in rank order, of [half-slab g | half-slab 2P-1-g])
-    balanced = batched and not args.as_rank and args.slabs != "contiguous" and H % (2 * world) == 0
+    # concatenation, in rank order, of [half-slab g | half-slab P+g])
+    balanced = batched and not args.as_rank and args.slabs == "balanced" and H % (2 * world) == 0
     pieces = balanced_slabs(H, rank, world) if balanced else [(r0, r1)]
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
@@ -453,7 +455,7 @@ def main():
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
                                     if batched and args.batch_call != "off" else "per frame"),
-                       "rows_per_rank": ("two half-slabs, g and 2P-1-g of 2P" if balanced else "one contiguous slab"),
+                       "rows_per_rank": ("two half-slabs, g and P+g of 2P" if balanced else "one contiguous slab"),
                        "collection": "none" if (not use_dist or frames_par) else
                                      (f"all-to-all per {world} frames, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},

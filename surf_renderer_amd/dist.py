@@ -24,14 +24,15 @@ def row_slab(height: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def balanced_slabs(height: int, rank: int, world: int) -> List[Tuple[int, int]]:
-    """Two half-slabs per rank, g and 2P-1-g of 2P equal ones: an outer and an inner part of the image, so that a scene
-    that is densest in the middle loads every rank alike.  Needs height % (2 * world) == 0."""
+    """Two half-slabs per rank, g and P+g of 2P equal ones.  For a scene whose density is symmetric about the image
+    centre and grows towards it, slab g (upper half: the farther down, the busier) and slab P+g (lower half: the farther
+    down, the emptier) add up to about the same load for every rank.  Needs height % (2 * world) == 0."""
     if height % (2 * world):
         raise ValueError(f"balanced slabs need height % {2 * world} == 0, got {height}")
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"rank {rank} of {world}")
     hh = height // (2 * world)
-    a, b = rank, 2 * world - 1 - rank
+    a, b = rank, world + rank
     return [(a * hh, (a + 1) * hh), (b * hh, (b + 1) * hh)]
 
 
