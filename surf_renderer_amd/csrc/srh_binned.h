@@ -230,7 +230,15 @@ __device__ __forceinline__ bool key_saturated(int32_t key) { return ((uint32_t)k
 __device__ __forceinline__ uint32_t key_ordinal(int32_t key) { return ((uint32_t)key & kOrdMask) - 1u; }
 
 // fp32 LOWER bound of the ray distance a key stands for (rcp is good to 1 ulp; the factor covers it)
-__device__ __forceinline__ float inv_to_bound(float inv_upper) { return __builtin_amdgcn_rcpf(inv_upper) * 0.9999995f; }
+// Does a candidate whose inverse-depth bound is `inv` (>= 1 / t of any valid hit of it) still "reach" a pixel whose
+// confirmed depth is at most `bound` -- could it win or tie?  Only if inv >= 1 / bound; compared against
+//   reach = min((1 - 1e-6) / bound, kReachMax).
+// The clamp makes candidates WITHOUT an estimate (inv = kNoEstimate, or a withdrawn estimate's 1e30 / |D|) reach
+// every depth, including bound = 0 and negative depths, which are valid hits when near <= 0 (the numpy backend's
+// sphere sentinel t = 0 ties across spheres and must go to the lowest index); a real estimate stays below kReachMax
+// unless the hit is closer than 1e-25, where it reaches anyway.  bound = +inf (nothing confirmed) gives reach 0.
+constexpr float kReachMax = 1.0e25f;
+__device__ __forceinline__ float reach_of(float bound) { return fminf(__builtin_amdgcn_rcpf(bound) * 0.999999f, kReachMax); }
 __device__ __forceinline__ float key_inv(int32_t key) { return __uint_as_float((uint32_t)key | kOrdMask); }   // >= 1 / t
 
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
@@ -459,7 +467,7 @@ __device__ __forceinline__ void resweep_list(const FrameDev& F, const SegDev& S,
     f32x2 inv[2];
     pair_bounds<TYPE, PRETEST>(R, cf, rf, rlen, sel, inv);
     const float iv = inv[0][0];
-    const bool need = open && sel[0] && iv > 0.0f && inv_to_bound(iv * 1.0000005f) <= bound;
+    const bool need = open && sel[0] && iv > 0.0f && iv >= reach_of(bound);
     if (__builtin_amdgcn_ballot_w64(need)) {
       if (need) {
         const double* R64 = S.rec64 + (size_t)(g - S.first) * kRec64Stride[TYPE];
@@ -493,7 +501,7 @@ __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, co
     f32x2 inv[2];
     pair_bounds<TYPE, PRETEST>(R, P.cf, P.rf, P.rlen, sel, inv);
     const float iv = inv[0][0];
-    if (sel[0] && iv > 0.0f && inv_to_bound(iv * 1.0000005f) <= P.bound && g != P.g1 && g != P.g2)
+    if (sel[0] && iv > 0.0f && iv >= reach_of(P.bound) && g != P.g1 && g != P.g2)
       confirm_global<TCH>(F, g, d, best, besti);
   }
 }
@@ -866,7 +874,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
         const int32_t keys[3] = {p.k1, p.k2, p.k3};
         bool saturated = false;
-        // a key still "reaches" the confirmed depth iff its inverse-depth bound is >= reach = (1 - 1e-6) / bound
+        // a key still "reaches" the confirmed depth iff its inverse-depth bound is >= reach_of(bound)
         // (one reciprocal per confirmation instead of one per key; 0 while nothing is confirmed)
         float reach = 0.0f;
 #pragma unroll
@@ -882,7 +890,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
               if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
               else confirm_global<TCH>(F, g, d, best, besti);
               bound = float_above(best);
-              reach = __builtin_amdgcn_rcpf(bound) * 0.999999f;     // bound = inf (a miss) gives 0 again
+              reach = reach_of(bound);                  // bound = inf (a miss) gives 0 again
             }
           }
         }
