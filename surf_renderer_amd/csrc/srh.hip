@@ -64,6 +64,9 @@ __device__ inline bool ball_misses_slab(const FrameDev& F, const double x[3], do
 // before any of the per-frame records is computed, and are simply not binned (no list refers to their records)
 __device__ inline bool primitive_misses_slab(const FrameDev& F, const SegDev& S, int i) {
   double x[3], rho;
+  // numpy semantics, near <= 0: a sphere whose line a ray MISSES yields the valid distance 0 (Q2) -- on every pixel
+  // of the image, wherever the sphere projects; it can never be culled
+  if (S.type == SRH_PRIM_SPHERE && !(F.near_clip > 0.0)) return false;
   if (S.type == SRH_PRIM_DISK || S.type == SRH_PRIM_SPHERE) {
     const float* c = S.pos + 4 * (size_t)i;
     for (int k = 0; k < 3; ++k) x[k] = (double)c[k] - F.o[k];

@@ -385,3 +385,45 @@ def test_sphere_cloud_with_near_zero():
     scene["objects"]["sphere"] = {"pos": d["pos"], "radius": d["radius"], "material_idx": d["material_idx"]}
     scene["camera"]["near"] = 0.0
     _modes_identical(scene, modes=("exact", "binned"))
+
+
+@pytest.mark.gpu
+def test_fuzz_slabs_torch_shading_and_views():
+    """150 random scenes through the other entry points: torch shading exact vs binned, a random row slab against the
+    rows of the full frame (the slab path culls primitives by their bounding ball -- this fuzz caught spheres being
+    culled although near <= 0 makes a missed sphere a valid hit at t = 0 on every pixel), and a batch of views against
+    per-view renders."""
+    from surf_renderer_amd import render, render_views
+    rng = np.random.RandomState(77)
+
+    def same(a, b, what):
+        for k in ("nearest", "depth", "image"):
+            x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+            assert np.array_equal(x, y, equal_nan=True), f"{what}: {k} differs on {(x != y).sum()} values"
+
+    for it in range(150):
+        sc = _random_scene(rng)
+        H = sc["camera"]["viewport"][3]
+        sc["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01]], dtype=np.float32)
+        sc["lights"]["ambient"] = np.array([0.01, 0.02, 0.01], dtype=np.float32)
+        sc["materials"]["coeffs"] = np.array([[1, 0, 0], [0.7, 0.3, 5], [0.5, 0.5, 20]], dtype=np.float32)
+        ds = bool(rng.randint(2))
+        same(render(sc, device="cuda:0", mode="exact", shading="torch", double_sided=ds),
+             render(sc, device="cuda:0", mode="binned", shading="torch", double_sided=ds,
+                    waves_per_tile=int(rng.choice([1, 4]))), f"scene {it} torch shading")
+        full = render(sc, device="cuda:0")
+        r0 = int(rng.randint(0, H - 1))
+        r1 = int(rng.randint(r0 + 1, H + 1))
+        same({k: full[k][r0:r1] for k in ("nearest", "depth", "image")}, render(sc, device="cuda:0", rows=(r0, r1)),
+             f"scene {it} rows {r0}:{r1}")
+        if it % 5 == 0:
+            cams = []
+            for _ in range(3):
+                e = rng.normal(size=3)
+                e = e / np.linalg.norm(e) * 3.0
+                cams.append(dict(sc["camera"], eye=[*map(float, e), 1.0]))
+            vb = render_views(sc, cams, device="cuda:0")
+            for i, cam in enumerate(cams):
+                one = render({**sc, "camera": cam}, device="cuda:0")
+                same({"image": vb["image"][i], "depth": vb["depth"][i], "nearest": vb["nearest"][i].to(torch.int64)},
+                     one, f"scene {it} view {i}")
