@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 6
+#define SRH_ABI_VERSION 7
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -56,7 +56,7 @@ enum {
 };
 
 /* scene['camera'] (numpy/renderer.py:145-169, numpy/ops.py:88-115).  Host memory, float64.
- * The caller applies the reference's float32 detour for list-typed at/up before filling this. */
+ * The caller applies the reference's float32 detour for list-typed at/up before filling this (see up_is_unit). */
 typedef struct SrhCamera {
   double eye[4];          /* w must be 1 */
   double at[4];
@@ -68,7 +68,9 @@ typedef struct SrhCamera {
   int32_t viewport[4];    /* x0, y0, x1, y1; W = x1 - x0, H = y1 - y0 */
   int32_t ortho;          /* 1: orthographic projection (torch/utils.py:461-468) -- SRH_SHADING_TORCH only (the numpy
                              backend has none), forward only, all pairs in fp64; 0: perspective */
-  int32_t pad;
+  int32_t up_is_unit;     /* 1: `up` is already the camera's y axis and is used as given.  The reference normalises a
+                             list-typed `up` in float32 arithmetic (numpy/ops.py:99,109), which the host repeats with
+                             the same numpy call before filling this; 0: y = up / |up| in float64 */
 } SrhCamera;
 
 /* one entry of scene['objects']: a batch of primitives of one type (device pointers) */

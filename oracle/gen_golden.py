@@ -7,6 +7,7 @@ loaders), renders each golden case and stores inputs + expected outputs as data.
 reference's code is written anywhere; the GPU box never sees /root/reference.
 
     python oracle/gen_golden.py            # (re)writes tests/golden/
+    python oracle/gen_golden.py g8k        # only the cases whose names start with g8k
 
 Cases: g1 demo scene, g2 demo + planes (all four primitive types), g3 basic.json,
 g4 halfbox_sphere_cube.json, g5 bunny.splat recipe, g6 bunny.obj mesh, g7 synthetic disc cloud,
@@ -49,7 +50,12 @@ def ref_render(scene):
     return {k: np.array(res[k]) for k in ("image", "depth", "nearest")}
 
 
+ONLY = sys.argv[1:]          # optional name prefixes: regenerate just those cases
+
+
 def emit(name, scene, note):
+    if ONLY and not any(name.startswith(p) for p in ONLY):
+        return
     out = ref_render(scene)
     save_case(os.path.join(OUT, name + ".npz"), scene, out, note)
     hit = np.isfinite(out["depth"]).mean()
@@ -198,6 +204,14 @@ def main():
     emit("g8j_array_camera_reordered", s,
          "ndarray-typed eye/at/up that are NOT fp32-representable (no float32 detour, Q11); dict order "
          "triangle, sphere, disk")
+
+    s = strip(synthetic.demo_scene(40, 30))
+    s["camera"]["eye"] = [0.3, 1.7, 9.1, 1.0]
+    s["camera"]["at"] = [0.1, -0.2, 0.05, 1.0]
+    s["camera"]["up"] = [0.3, 1.7, -0.45, 0.0]
+    emit("g8k_list_camera_unnormalised_up", s,
+         "list-typed at/up that are neither fp32-representable nor unit: the float32 detour rounds them AND "
+         "normalises up in float32 (Q11, numpy/ops.py:95-109)")
 
 
 if __name__ == "__main__":

@@ -29,6 +29,12 @@ def unit3(u):
     return u / np.where(np.abs(den) > 0, den, 1.0)
 
 
+def cam_vec(v):
+    """A camera vector as the torch backend holds it: a float32 tensor (make_torch_var, torch/render.py:81-100), whatever
+    container the scene used -- its values, in float64."""
+    return np.asarray(v, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
 def is_ortho(camera):
     return str(camera.get('proj_type', 'perspective')) in ('ortho', 'orthographic')
 
@@ -43,9 +49,9 @@ def generate_rays_ortho(camera):
     x, y = np.meshgrid(np.linspace(-1, 1, W), np.linspace(1, -1, H))
     x = x.ravel() * (w / 2)
     y = y.ravel() * (h / 2)
-    eye = np.asarray(camera['eye'], dtype=np.float64)[:3]
-    at = np.asarray(camera['at'], dtype=np.float64)[:3]
-    up = np.asarray(camera['up'], dtype=np.float64)[:3]
+    eye = cam_vec(camera['eye'])[:3]
+    at = cam_vec(camera['at'])[:3]
+    up = cam_vec(camera['up'])[:3]
     z = unit3(eye - at)
     xb = unit3(np.cross(unit3(up), z))
     yb = np.cross(z, xb)
@@ -124,7 +130,7 @@ def shade(scene, res, vis=None, double_sided=False, use_quartic=False):
     H, W = res['depth'].shape
     hit = (res['depth'] <= cam['far']).reshape(-1)
     material_idx = np.concatenate([np.asarray(g['material_idx']) for g in scene['objects'].values()]).astype(np.int64)
-    eye = np.asarray(cam['eye'], dtype=np.float64)[:3]
+    eye = cam_vec(cam['eye'])[:3]
     with np.errstate(all='ignore'):
         im = _fragment_shader(scene, eye, res['pos'].reshape(-1, 3), res['normal'].reshape(-1, 3),
                               material_idx[res['nearest'].reshape(-1)], double_sided, use_quartic, vis)
@@ -210,9 +216,9 @@ def generate_rays(camera):
     x, y = np.meshgrid(np.linspace(-1, 1, W), np.linspace(1, -1, H))
     x = x.ravel() * (w / 2)
     y = y.ravel() * (h / 2)
-    eye = np.asarray(camera['eye'], dtype=np.float64)[:3]
-    at = np.asarray(camera['at'], dtype=np.float64)[:3]
-    up = np.asarray(camera['up'], dtype=np.float64)[:3]
+    eye = cam_vec(camera['eye'])[:3]
+    at = cam_vec(camera['at'])[:3]
+    up = cam_vec(camera['up'])[:3]
     z = unit3(eye - at)
     xb = unit3(np.cross(unit3(up), z))
     yb = np.cross(z, xb)

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -24,7 +24,7 @@ class SrhCamera(C.Structure):
     _fields_ = [("eye", C.c_double * 4), ("at", C.c_double * 4), ("up", C.c_double * 4),
                 ("fovy", C.c_double), ("focal_length", C.c_double),
                 ("near_clip", C.c_double), ("far_clip", C.c_double),
-                ("viewport", C.c_int32 * 4), ("ortho", C.c_int32), ("pad", C.c_int32)]
+                ("viewport", C.c_int32 * 4), ("ortho", C.c_int32), ("up_is_unit", C.c_int32)]
 
 
 class SrhSegment(C.Structure):

@@ -537,7 +537,7 @@ int camera_to_frame(const SrhCamera* cam, FrameDev* F, bool orthonormal = false)
   double ul = sqrt(cam->up[0] * cam->up[0] + cam->up[1] * cam->up[1] + cam->up[2] * cam->up[2]);
   if (!(zl > 0) || !(ul > 0)) return fail(SRH_E_CAMERA, "degenerate camera: eye == at or up == 0");
   double y[3];
-  for (int i = 0; i < 3; ++i) { z[i] /= zl; y[i] = cam->up[i] / ul; }
+  for (int i = 0; i < 3; ++i) { z[i] /= zl; y[i] = cam->up_is_unit ? cam->up[i] : cam->up[i] / ul; }
   double x[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
   if (orthonormal) {
     // torch backend (torch/utils.py:402-427): x = unit(cross(unit(up), z)), y = cross(z, x)

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .scene import PRIM_CODE, _OBJ_FIELDS
+from .scene import PRIM_CODE, _OBJ_FIELDS, unit_up
 
 # keyword arguments of the torch backend's render() that callers pass routinely (torch/renderer.py:
 # 152-168, 233-245, 291, 326-327); the hip backend accepts them so call sites need no edits.
@@ -216,9 +216,10 @@ def _shape_of(x):
     return np.asarray(x).shape
 
 
-def camera_struct(camera: Dict[str, Any]) -> _lib.SrhCamera:
+def camera_struct(camera: Dict[str, Any], shading: str = "numpy") -> _lib.SrhCamera:
     """scene['camera'] -> SrhCamera.  List-typed ``at`` / ``up`` take the reference's float32 detour
-    (numpy/ops.py:95-100, quirk Q11); arrays and tensors are taken at full precision."""
+    (numpy/ops.py:95-100, quirk Q11), which for the numpy backend's semantics includes normalising ``up`` in
+    float32; arrays and tensors are taken at full precision."""
     def vec(val, f32_if_list: bool):
         if isinstance(val, torch.Tensor):
             return val.detach().cpu().double().numpy().reshape(-1)
@@ -233,10 +234,20 @@ def camera_struct(camera: Dict[str, Any]) -> _lib.SrhCamera:
 
     cam = _lib.SrhCamera()
     eye, at, up = vec(camera["eye"], False), vec(camera["at"], True), vec(camera["up"], True)
+    if shading == "torch":
+        # the torch backend holds all three as float32 tensors (make_torch_var, torch/render.py:81-100)
+        eye, at, up = (v.astype(np.float32).astype(np.float64) for v in (eye, at, up))
     if up.size == 3:
         up = np.append(up, 0.0)
     if eye.size != 4 or at.size != 4 or up.size != 4:
         raise ValueError("camera.eye / camera.at must be homogeneous 4-vectors, camera.up a 3- or 4-vector")
+    if shading == "numpy" and isinstance(camera["up"], (list, tuple)):
+        # the reference normalises a list-typed up in float32 (numpy/ops.py:99,109): hand over the finished y axis
+        with np.errstate(all="ignore"):
+            unit = unit_up(camera["up"], up)
+        if np.all(np.isfinite(unit)):
+            up = np.append(unit, 0.0)
+            cam.up_is_unit = 1
     cam.eye[:] = eye.tolist()
     cam.at[:] = at.tolist()
     cam.up[:] = up.tolist()
@@ -494,7 +505,7 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` / ``use_quartic`` as in ``render``.  Forward only."""
     device = torch.device(device)
     buf = flatten_scene(scene, device)
-    cams = [camera_struct(c) for c in cameras]
+    cams = [camera_struct(c, shading_kw.get("shading", "numpy")) for c in cameras]
     if not cams:
         raise ValueError("no cameras")
     width, height = frame_size(cams[0])
@@ -590,9 +601,9 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
         raise TypeError(f"render() got unexpected keyword arguments {sorted(unknown)}")
     device = torch.device(params.get("device", "cuda"))
     buf = flatten_scene(scene, device, validate=params.get("validate", True), keep_graph=torch.is_grad_enabled())
-    cam = camera_struct(scene["camera"])
-    rows, mode = params.get("rows"), params.get("mode", "auto")
     shading = params.get("shading", "numpy")
+    cam = camera_struct(scene["camera"], shading)
+    rows, mode = params.get("rows"), params.get("mode", "auto")
     if shading not in _lib.SHADING:
         raise ValueError(f"shading must be 'numpy' or 'torch', got {shading!r}")
     shadow = bool(params.get("shadow", False))

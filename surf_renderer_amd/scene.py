@@ -295,7 +295,7 @@ class CameraFrame:
 
     Follows numpy/renderer.py:145-169 and numpy/ops.py:88-115 including their quirks: the basis
     is y = up/|up|, z = (eye-at)/|eye-at|, x = cross(y, z) *not* re-normalised, and
-    list-typed ``at`` / ``up`` pass through float32 first (Q11).
+    list-typed ``at`` / ``up`` pass through float32 first, ``up`` is also normalised there (Q11).
     """
     width: int
     height: int
@@ -309,6 +309,17 @@ class CameraFrame:
     focal: float
     near: float
     far: float
+
+
+def unit_up(given, up64: np.ndarray) -> np.ndarray:
+    """The camera's y axis, up / |up| (numpy/ops.py:109).  A list-typed ``up`` is a float32 array at that point
+    (:99), so norm and division happen in float32 -- repeated here with the same numpy calls -- and everything after
+    (the cross product with the float64 z) is float64 again."""
+    if isinstance(given, (list, tuple)):
+        up32 = np.asarray(given, dtype=np.float32).reshape(-1)[:3]
+        return (up32 / np.linalg.norm(up32, 2)).astype(np.float64)
+    up64 = np.asarray(up64, dtype=np.float64).reshape(-1)[:3]
+    return up64 / np.linalg.norm(up64, 2)
 
 
 def camera_frame(camera: Dict[str, Any]) -> CameraFrame:
@@ -339,7 +350,7 @@ def camera_frame(camera: Dict[str, Any]) -> CameraFrame:
         raise ValueError("camera.eye and camera.at must be homogeneous 4-vectors")
     z = eye - at
     z = (z / np.linalg.norm(z, 2))[:3]
-    y = up / np.linalg.norm(up, 2)
+    y = unit_up(camera["up"], up)
     x = np.cross(y, z)
     if eye[3] != 1.0:
         # the reference places the ray origin at eye (w kept) while the view matrix uses eye/w;

@@ -427,3 +427,36 @@ def test_fuzz_slabs_torch_shading_and_views():
                 one = render({**sc, "camera": cam}, device="cuda:0")
                 same({"image": vb["image"][i], "depth": vb["depth"][i], "nearest": vb["nearest"][i].to(torch.int64)},
                      one, f"scene {it} view {i}")
+
+
+@pytest.mark.gpu
+def test_fuzz_against_the_oracles():
+    """60 small random scenes (list-typed, non-unit, non-fp32 camera vectors; all primitive types; near down to 0)
+    against the CPU oracles at the stated tolerance: numpy semantics, then Phong / attenuation / ambient semantics
+    in both projections.  This is the test that caught the float32 normalisation of a list-typed `up` (Q11)."""
+    from surf_renderer_amd import render
+    from surf_renderer_amd.scene import scene_to_numpy
+    from oracle import np_oracle_tch
+    rng = np.random.RandomState(77)
+    done = 0
+    while done < 60:
+        scene = _random_scene(rng)
+        W, H = scene["camera"]["viewport"][2:]
+        if W * H > 64 * 80 or sum(len(g["material_idx"]) for g in scene["objects"].values()) > 800:
+            continue
+        done += 1
+        assert_parity(_render(scene), np_oracle.render(scene_to_numpy(scene, round_fp32=True)))
+        scene["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01]], dtype=np.float32)
+        scene["lights"]["ambient"] = np.array([0.01, 0.02, 0.01], dtype=np.float32)
+        scene["materials"]["coeffs"] = np.array([[1, 0, 0], [0.7, 0.3, 5], [0.5, 0.5, 20]], dtype=np.float32)
+        scene["camera"]["near"] = max(scene["camera"]["near"], 0.01)
+        for proj in ("perspective", "ortho"):
+            scene["camera"]["proj_type"] = proj
+            ds = bool(rng.randint(2))
+            sc = scene_to_numpy(scene, round_fp32=True)
+            sc["camera"]["proj_type"] = proj
+            want = np_oracle_tch.render(sc, double_sided=ds)
+            res = render(scene, device="cuda:0", shading="torch", double_sided=ds)
+            same = res["nearest"].cpu().numpy() == want["nearest"]
+            assert same.all(), f"scene {done} ({proj}): nearest differs on {(~same).sum()} pixels"
+            np.testing.assert_allclose(res["image"].cpu().numpy(), want["image"], rtol=IMAGE_RTOL, atol=IMAGE_ATOL)
