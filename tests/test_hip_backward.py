@@ -212,3 +212,54 @@ def test_torch_shading_backward_with_shadows():
         w = want[key].reshape(got.shape)
         # a handful of grazing shadow rays may be decided differently: 0.5 % of the largest entry
         np.testing.assert_allclose(got, w, atol=5e-3 * max(np.abs(w).max(), 1e-9) + 1e-6, err_msg=key)
+
+
+def test_fuzz_backward_against_the_gradient_oracles():
+    """40 small random mixed scenes (all primitive types, cameras inside the cloud, sub-pixel to screen-filling
+    primitives): the numpy-semantics backward, then the Phong backward with random double_sided / use_quartic /
+    shadow, each against the fp64 gradient oracle.  Tolerance 5e-4 of the largest entry per array (random scenes
+    hold grazing hits whose fp32 atomic sums cancel harder than the curated scenes above)."""
+    from oracle import np_oracle_tch
+    from surf_renderer_amd import render
+    from surf_renderer_amd.scene import scene_to_numpy
+    from test_hip_parity import _random_scene
+    rng = np.random.RandomState(41)
+
+    def compare(tag, got, want, tol):
+        for key, w in want.items():
+            assert np.all(np.isfinite(w)), (tag, key)
+            g = got[key].reshape(w.shape)
+            np.testing.assert_allclose(g, w, rtol=0, atol=tol * max(np.abs(w).max(), 1e-9) + 1e-6, err_msg=f"{tag} {key}")
+
+    done = 0
+    while done < 40:
+        scene = _random_scene(rng)
+        W, H = scene["camera"]["viewport"][2:]
+        if W * H > 64 * 80 or sum(len(g["material_idx"]) for g in scene["objects"].values()) > 400:
+            continue
+        done += 1
+        scene["camera"]["near"] = max(scene["camera"]["near"], 0.01)      # near <= 0: missed spheres hit with a 0/0 normal
+        sc = scene_to_numpy(scene, round_fp32=True)
+        g_img = rng.uniform(-1, 1, size=(H, W, 3)).astype(np.float32).astype(np.float64)
+        g_dep = rng.uniform(-1, 1, size=(H, W)).astype(np.float32).astype(np.float64)
+        got, fwd = _hip_gradients(sc, g_img, g_dep)
+        compare(f"scene {done} numpy", got, torch_oracle.gradients(sc, g_img, g_dep, ref=fwd), 5e-4)
+
+        sc["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01]])
+        sc["lights"]["ambient"] = np.array([0.01, 0.02, 0.01])
+        sc["materials"]["coeffs"] = np.array([[1, 0, 0], [0.7, 0.3, 5], [0.5, 0.5, 20]])
+        kw = {"double_sided": bool(rng.randint(2)), "use_quartic": bool(rng.randint(2))}
+        shadow = bool(rng.randint(2))
+        ref = np_oracle_tch.render(sc, shadow=shadow, **kw)
+        leaf_scene, leaves = _leaf_scene_tch(sc)
+        res = render(leaf_scene, device="cuda:0", shading="torch", shadow=shadow, **kw)
+        assert np.array_equal(res["nearest"].cpu().numpy(), ref["nearest"])
+        dep, far = res["depth"], float(sc["camera"]["far"])
+        loss = torch.sum(res["image"] * torch.as_tensor(g_img, dtype=torch.float32, device=dep.device)) + \
+            torch.sum(torch.where(dep <= far, dep * torch.as_tensor(g_dep, dtype=torch.float32, device=dep.device),
+                                  torch.zeros_like(dep)))
+        loss.backward()
+        want = torch_oracle.gradients_tch(sc, g_img, g_dep, ref=ref, visibility=ref["visibility"] if shadow else None, **kw)
+        got = {k: (t.grad.cpu().numpy().astype(np.float64) if t.grad is not None else np.zeros(tuple(t.shape)))
+               for k, t in leaves.items()}
+        compare(f"scene {done} torch {kw} shadow={shadow}", got, want, 5e-3 if shadow else 5e-4)
