@@ -16,6 +16,7 @@ There is no CPU fallback: without a GPU or without libsrh.so these functions rai
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -37,13 +38,62 @@ def _require_gpu(device: torch.device) -> None:
 
 
 def _as_tensor(x, dtype: torch.dtype, device: torch.device, keep_graph: bool = False) -> torch.Tensor:
-    """Contiguous device tensor of ``x``.  With ``keep_graph`` a tensor that requires grad stays attached to the
-    autograd graph (the casts and copies are differentiable), so gradients reach the caller's leaf."""
+    """Contiguous tensor of ``x`` in ``dtype``: on ``device`` if ``x`` already lives there or takes part in autograd
+    (with ``keep_graph`` a tensor that requires grad stays attached to the graph -- casts and copies are
+    differentiable -- so gradients reach the caller's leaf); otherwise still in host memory, for ``_upload`` to send
+    with everything else in one transfer."""
     if isinstance(x, torch.Tensor):
         t = x if (keep_graph and x.requires_grad) else x.detach()
-    else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
-    return t.to(device=device, dtype=dtype).contiguous()
+        if t.is_cuda or t.requires_grad:
+            return t.to(device=device, dtype=dtype).contiguous()
+        x = t.numpy()
+    # host leaves are converted and packed with numpy (plain single-threaded copies): torch's CPU operators go through
+    # its OpenMP pool, which on a box with fewer cores than threads costs milliseconds per frame while the GPU runs
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=_NP_DTYPE[dtype]))
+
+
+_NP_DTYPE = {torch.float32: np.float32, torch.int32: np.int32}
+_STAGING: Dict[torch.device, Tuple[torch.Tensor, torch.cuda.Event]] = {}
+_STAGING_LOCK = threading.Lock()
+_UPLOAD_ALIGN = 256
+
+
+def _upload(tensors: Dict[str, torch.Tensor], device: torch.device) -> None:
+    """Move every host tensor of ``tensors`` to the device in ONE host-to-device copy: the leaves are packed into a
+    pinned staging buffer (kept per device, guarded by an event so that a new frame's packing waits for the previous
+    frame's copy) and the device side is carved into typed views.  A scene is ~10 small arrays; sent one by one from
+    pageable memory each costs a synchronous copy of ~0.6 ms, which was all of render(scene)'s time."""
+    host = [(k, t) for k, t in tensors.items() if not t.is_cuda]
+    if not host:
+        return
+    offsets, total = [], 0
+    for _, t in host:
+        offsets.append(total)
+        total += -(-t.numel() * t.element_size() // _UPLOAD_ALIGN) * _UPLOAD_ALIGN
+    total = max(total, _UPLOAD_ALIGN)
+    with _STAGING_LOCK:
+        _upload_locked(tensors, device, host, offsets, total)
+
+
+def _upload_locked(tensors, device, host, offsets, total) -> None:
+    entry = _STAGING.get(device)
+    if entry is not None:
+        entry[1].synchronize()
+    if entry is None or entry[0].numel() < total:
+        entry = (torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+        _STAGING[device] = entry
+    staging, done = entry
+    staging_np = staging.numpy()
+    for (_, t), off in zip(host, offsets):
+        n = t.numel() * t.element_size()
+        if n:
+            staging_np[off:off + n] = t.numpy().reshape(-1).view(np.uint8)
+    packed = torch.empty(total, dtype=torch.uint8, device=device)
+    packed.copy_(staging[:total], non_blocking=True)
+    done.record(torch.cuda.current_stream(device))
+    for (k, t), off in zip(host, offsets):
+        n = t.numel() * t.element_size()
+        tensors[k] = packed[off:off + n].view(t.dtype).reshape(t.shape)
 
 
 def _host_view(x) -> Optional[np.ndarray]:
@@ -145,7 +195,6 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
                 elif name == "normal":
                     _check_w(f"{kind}.{name}", None if host is None else host.reshape(-1, 4), 0.0)
             tensors[f"{kind}.{name}"] = t
-            setattr(seg, name, t.data_ptr())
         mi_host = _host_view(grp["material_idx"])
         if validate and mi_host is not None and mi_host.size:
             if mi_host.min() < 0 or mi_host.max() >= n_mat:
@@ -156,7 +205,6 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
         if count == 0:
             raise ValueError(f"{kind}: empty batch")
         tensors[f"{kind}.material_idx"] = mi
-        seg.material_idx = mi.data_ptr()
         seg.count = count
         kinds.append(kind)
         counts.append(count)
@@ -177,26 +225,33 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
         if ci is not None and ci.size and (ci.min() < 0 or ci.max() >= colors.shape[0]):
             raise IndexError("lights.color_idx out of range for the colour table")
     tensors.update({"lights.pos": lpos, "lights.color_idx": lidx, "colors": colors, "materials.albedo": albedo})
-    ls = _lib.SrhLights(n_lights=lpos.shape[0], n_colors=colors.shape[0], pos=lpos.data_ptr(),
-                        color_idx=lidx.data_ptr(), colors=colors.data_ptr())
-    ms = _lib.SrhMaterials(n_materials=albedo.shape[0], albedo=albedo.data_ptr())
     # inputs of the torch backend's shading model only (ignored by the numpy one, numpy/renderer.py:234-255)
     if "attenuation" in lights:
         att = _as_tensor(lights["attenuation"], f32, device, keep_graph).reshape(-1, 3)
         if att.shape[0] != lpos.shape[0]:
             raise ValueError("lights.attenuation must have one (kc, kl, kq) row per light")
         tensors["lights.attenuation"] = att
-        ls.attenuation = att.data_ptr()
     if "ambient" in lights:
-        amb = _as_tensor(lights["ambient"], f32, device, keep_graph).reshape(3)
-        tensors["lights.ambient"] = amb
-        ls.ambient = amb.data_ptr()
+        tensors["lights.ambient"] = _as_tensor(lights["ambient"], f32, device, keep_graph).reshape(3)
     if "coeffs" in scene["materials"]:
         cfs = _as_tensor(scene["materials"]["coeffs"], f32, device, keep_graph).reshape(-1, 3)
         if cfs.shape[0] != albedo.shape[0]:
             raise ValueError("materials.coeffs must have one row per material")
         tensors["materials.coeffs"] = cfs
-        ms.coeffs = cfs.data_ptr()
+
+    _upload(tensors, device)
+    for s, kind in enumerate(kinds):
+        for name in _OBJ_FIELDS[kind] + ("material_idx",):
+            setattr(ob.seg[s], name, tensors[f"{kind}.{name}"].data_ptr())
+    ls = _lib.SrhLights(n_lights=lpos.shape[0], n_colors=colors.shape[0], pos=tensors["lights.pos"].data_ptr(),
+                        color_idx=tensors["lights.color_idx"].data_ptr(), colors=tensors["colors"].data_ptr())
+    ms = _lib.SrhMaterials(n_materials=albedo.shape[0], albedo=tensors["materials.albedo"].data_ptr())
+    if "lights.attenuation" in tensors:
+        ls.attenuation = tensors["lights.attenuation"].data_ptr()
+    if "lights.ambient" in tensors:
+        ls.ambient = tensors["lights.ambient"].data_ptr()
+    if "materials.coeffs" in tensors:
+        ms.coeffs = tensors["materials.coeffs"].data_ptr()
 
     gamma = None
     if "tonemap" in scene:
@@ -568,6 +623,20 @@ class RenderResult(dict):
     def __init__(self, camera, device, *args, **kw):
         super().__init__(*args, **kw)
         self._camera, self._device = camera, device
+
+    def numpy(self, *keys: str) -> Dict[str, np.ndarray]:
+        """Host ndarrays of the named entries (default image, depth, nearest) -- what the reference's numpy backend
+        returns.  The copies go through pinned host memory from torch's caching host allocator, asynchronously and
+        with one wait at the end: ~10x the rate of ``.cpu()`` on a 2048 x 2048 frame.  The arrays own their memory."""
+        keys = keys or ("image", "depth", "nearest")
+        stream = torch.cuda.current_stream(self._device)
+        host = {}
+        for k in keys:
+            t = self[k].detach()
+            host[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host[k].copy_(t, non_blocking=True)
+        stream.synchronize()
+        return {k: h.numpy() for k, h in host.items()}
 
     def __missing__(self, key):
         if key == "ray_dir":

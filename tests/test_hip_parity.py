@@ -460,3 +460,30 @@ def test_fuzz_against_the_oracles():
             same = res["nearest"].cpu().numpy() == want["nearest"]
             assert same.all(), f"scene {done} ({proj}): nearest differs on {(~same).sum()} pixels"
             np.testing.assert_allclose(res["image"].cpu().numpy(), want["image"], rtol=IMAGE_RTOL, atol=IMAGE_ATOL)
+
+
+@pytest.mark.gpu
+def test_host_scene_upload_and_pinned_readback():
+    """render(scene) with host leaves of mixed containers (float64 / float32 ndarrays, CPU tensors, lists) sends them
+    in one packed transfer: same frame as with leaves already on the device; and RenderResult.numpy() returns what
+    .cpu() does.  Two frames back to back share the staging buffer without the second overwriting the first."""
+    from surf_renderer_amd import render, synthetic
+    a = synthetic.demo_scene(96, 64, with_planes=True)
+    b = synthetic.disk_cloud_scene(500, 96, 64, radius=0.1, seed=2)
+    mixed = copy_scene = __import__("copy").deepcopy(a)
+    mixed["objects"]["disk"]["pos"] = torch.tensor(np.asarray(a["objects"]["disk"]["pos"], dtype=np.float64))
+    mixed["objects"]["sphere"]["radius"] = [float(r) for r in np.ravel(a["objects"]["sphere"]["radius"])]
+    mixed["colors"] = np.asarray(a["colors"], dtype=np.float32)
+    on_device = __import__("copy").deepcopy(a)
+    for grp in on_device["objects"].values():
+        for k in list(grp):
+            grp[k] = torch.tensor(np.asarray(grp[k]), device="cuda:0")
+    ra, rb = render(mixed, device="cuda:0"), render(b, device="cuda:0")      # b's upload must not disturb a's frame
+    rd = render(on_device, device="cuda:0")
+    for k in ("image", "depth", "nearest"):
+        assert torch.equal(ra[k], rd[k]), k
+    host = ra.numpy()
+    for k in ("image", "depth", "nearest"):
+        np.testing.assert_array_equal(host[k], ra[k].cpu().numpy())
+    assert_parity({k: v for k, v in rb.numpy().items()}, _render(b))
+    assert set(ra.numpy("depth")) == {"depth"}
