@@ -485,7 +485,9 @@ int check_objects(const SrhObjects* ob) {
     if (g.type == SRH_PRIM_TRIANGLE && !g.face) return fail(SRH_E_NULL, "segment %d: face is NULL", s);
     total += g.count;
   }
-  if (total > 0x7fffffffLL) return fail(SRH_E_RANGE, "too many primitives (%lld)", total);
+  // tile-list offsets are 32-bit and every primitive may own up to kMaxTilesPerPrim list entries
+  if (total > 0xffffffffLL / kMaxTilesPerPrim)
+    return fail(SRH_E_RANGE, "too many primitives (%lld): at most %lld per scene", total, 0xffffffffLL / kMaxTilesPerPrim);
   return SRH_OK;
 }
 

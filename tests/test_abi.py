@@ -73,6 +73,14 @@ def test_workspace_query_validates_its_input(lib):
     big = lib.srh_workspace_bytes(C.byref(ob), 2048, 2048)
     assert 0 < small < big and small % 256 == 0
     assert lib.srh_workspace_bytes(C.byref(ob), 0, 64) == 0
+    # the tile lists use 32-bit offsets with up to 64 entries per primitive: more than 2^26 primitives is refused
+    ob.n_segments = 2
+    ob.seg[1] = ob.seg[0]
+    ob.seg[0].count = ob.seg[1].count = (1 << 25) + 1
+    assert lib.srh_workspace_bytes(C.byref(ob), 64, 64) == 0
+    assert b"too many primitives" in lib.srh_last_error()
+    ob.seg[1].count = (1 << 25) - 2
+    assert lib.srh_workspace_bytes(C.byref(ob), 64, 64) > (1 << 34)
 
 
 def test_render_rejects_bad_arguments_before_touching_the_gpu(lib):

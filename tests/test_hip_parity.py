@@ -487,3 +487,18 @@ def test_host_scene_upload_and_pinned_readback():
         np.testing.assert_array_equal(host[k], ra[k].cpu().numpy())
     assert_parity({k: v for k, v in rb.numpy().items()}, _render(b))
     assert set(ra.numpy("depth")) == {"depth"}
+
+
+@pytest.mark.gpu
+def test_scale_millions_of_primitives_and_an_8k_frame():
+    """Sizes well beyond BASELINE's: 4 M sub-pixel discs (tile lists of ~4 k entries everywhere) and an 8192 x 8192
+    frame (262 144 tiles): the binned pipeline against the all-pairs mode, bit for bit."""
+    from surf_renderer_amd import render, synthetic
+    for scene in (synthetic.disk_cloud_scene(4_000_000, 512, 512, radius=0.003, seed=1),
+                  synthetic.disk_cloud_scene(20_000, 8192, 8192, radius=0.03, seed=2)):
+        a = render(scene, device="cuda:0", mode="binned")
+        b = render(scene, device="cuda:0", mode="fast")
+        assert 0.2 < torch.isfinite(a["depth"]).float().mean().item() < 0.99
+        for k in ("image", "depth", "nearest"):
+            assert torch.equal(a[k], b[k]), k
+        del a, b
