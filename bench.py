@@ -133,7 +133,13 @@ def main():
     if use_dist:
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        # SRH_BENCH_BACKEND=gloo (with SRH_BENCH_SINGLE_DEVICE=1): rehearsal of the multi-rank schedule on a one-GPU box,
+        # where RCCL refuses two ranks on one device
+        backend = os.environ.get("SRH_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from surf_renderer_amd import _lib, renderer, synthetic
     from surf_renderer_amd.dist import FrameBatcher, balanced_slabs, exchange_frames, gather_rows, row_slab
