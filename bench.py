@@ -37,11 +37,11 @@ VALU_F32_PEAK_TFLOPS = 157.3
 # med3, bfi, packed f32, fp64), which a SIMD issues at one wave-instruction per 4 cycles whatever the number of
 # waves (tools/ubench_valu.hip: 1.75-1.85 ns; only plain add/mul/logic reach 2 cycles): 1024 SIMDs x 2.4 GHz / 4.
 VALU_PEAK_GINSTR_S = 614.4
-# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_e_pmc_counters.txt)
-VALU_WAVE_INSTR_PER_LAUNCH = 49.9e6
-# HBM bytes of one render launch of the default workload from the PMC counters (same file): WRITE_SIZE 70 995 KiB +
-# FETCH_SIZE 18 025 KiB x 2 (the guide's gfx950 correction for the read side, worst case)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (70995 + 2 * 18025) * 1024.0
+# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_f_pmc_counters.txt)
+VALU_WAVE_INSTR_PER_LAUNCH = 49.2e6
+# HBM bytes of one render launch of the default workload from the PMC counters (same file): WRITE_SIZE 70 984 KiB +
+# FETCH_SIZE 18 014 KiB x 2 (the guide's gfx950 correction for the read side, worst case)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = (70984 + 2 * 18014) * 1024.0
 
 
 def parse():
@@ -468,7 +468,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None,
-                         "traffic_source": "profiles/r01_e_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                         "traffic_source": "profiles/r01_f_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes), constant" if default_workload else None,
                          "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes,
