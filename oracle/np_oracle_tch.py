@@ -1,7 +1,7 @@
 """CPU oracle for the reference's *torch* backend semantics -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 fp64 numpy restatement of the forward of ``diffrend/torch/renderer.py:136-355`` (perspective and orthographic
-projection; shadows as an UNPINNED extra, see light_visibility), the superset shading model that the hip backend offers as ``render(scene, shading='torch')``
+projection; shadows, see light_visibility), the superset shading model that the hip backend offers as ``render(scene, shading='torch')``
 (SURVEY.md section 8, row f1).  Differences from the numpy backend that this file reproduces:
   * camera basis orthonormalised: x = unit(cross(unit(up), z)), y = cross(z, x)        (torch/utils.py:402-427)
   * normals normalised over xyz only, with the reference's eps: u / sqrt(sum(u^2 + 1e-10))   (torch/utils.py:131-135)
@@ -101,8 +101,10 @@ def light_visibility(scene, res):
     """torch/renderer.py:291-314 (`shadow=True`): from every fragment a ray towards every light, started 0.1 along
     it; the light is visible unless some primitive OTHER than the fragment's own is hit closer than the light
     (distances measured from the shifted origin, the light's distance from the fragment itself, as the reference
-    does).  Returns (L, H*W) bool.  PARITY UNPINNED: the reference casts the result with
-    `.type(torch.cuda.FloatTensor)`, so its shadow path cannot run without CUDA and no fixture could be generated."""
+    does).  Returns (L, H*W) bool.  PINNED by tests/golden/s1*.npz: outputs of the reference's render(shadow=True),
+    generated on the CPU by oracle/gen_golden_shadow.py, which aliases `torch.cuda.FloatTensor` to `torch.FloatTensor`
+    in its own process because the reference casts the mask with `.type(torch.cuda.FloatTensor)` (:311); the
+    reference returns only the shaded image, which is what tests/test_oracle_tch.py compares."""
     cam = scene['camera']
     objs = {k: {f: np.asarray(v, dtype=np.float64) if f != 'material_idx' else np.asarray(v) for f, v in g.items()}
             for k, g in scene['objects'].items()}
@@ -231,7 +233,7 @@ def generate_rays(camera):
 def render(scene, double_sided=False, use_quartic=False, tile=2048, shadow=False):
     """Returns image (H,W,3), depth (H,W) with far+1 background, nearest (H,W), normal (H,W,3), pos (H,W,3)
     (normal / pos are 0 where nothing is hit).  With `shadow` also `visibility` (L,H,W) bool, and the image is
-    shaded with it (see light_visibility: that part of the oracle is UNPINNED)."""
+    shaded with it (see light_visibility)."""
     if shadow:
         res = render(scene, double_sided, use_quartic, tile)
         vis = light_visibility(scene, res)

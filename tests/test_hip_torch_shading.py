@@ -4,6 +4,8 @@ reference torch backend's own outputs (tests/golden/t*.npz, float32) and the fp6
 Tolerances: against the float32 reference as in tests/test_oracle_tch.py (<= 0.5 % of pixels may differ in hit /
 nearest at silhouettes; depth 2e-5 relative, image / normal 3e-4, pos 2e-4 elsewhere); against the fp64 oracle
 `nearest` identical, depth one fp32 ulp, image 2e-7 + 2e-6 |x|."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -80,8 +82,8 @@ def test_orthographic_projection_rules():
 @pytest.mark.parametrize("case", ["t2_mixed_specular_64x48", "t2_mixed_specular_64x48_ds", "t4_mixed_ortho_64x48",
                                   "t3_disk_cloud_64x64_ds"])
 def test_shadow_pass_matches_the_oracle(case):
-    """shadow=True: the all-pairs shadow-ray pass against the oracle's restatement of torch/renderer.py:291-314 (that
-    part of the oracle is unpinned -- the reference's shadow code needs CUDA tensors).  Both are fp64: the visibility
+    """shadow=True: the all-pairs shadow-ray pass against the oracle's restatement of torch/renderer.py:291-314 (pinned
+    by the reference's own shadow renders, tests/golden/s1*.npz).  Both are fp64: the visibility
     bits must agree except where a shadow ray grazes a primitive's edge (<= 0.2 % of hit pixels x lights), and the
     image must match wherever they do."""
     from surf_renderer_amd import render
@@ -104,3 +106,22 @@ def test_shadow_pass_matches_the_oracle(case):
     base = render(scene, device="cuda:0", shading="torch", **kw)
     assert not np.array_equal(base["image"].cpu().numpy(), res["image"].cpu().numpy())
     np.testing.assert_array_equal(base["depth"].cpu().numpy(), res["depth"].cpu().numpy())
+
+
+@pytest.mark.parametrize("case", ["s1a_mixed_shadow_64x48", "s1a_mixed_shadow_64x48_ds", "s1b_disk_cloud_shadow_64x64_ds"])
+def test_shadow_pass_matches_reference_torch_backend(case):
+    """render(shading='torch', shadow=True) against the reference's own render(shadow=True) (float32, CPU;
+    oracle/gen_golden_shadow.py): same tolerance as the unshadowed reference cases, a grazing shadow ray may flip on
+    <= 0.5 % of the pixels."""
+    import json
+    from conftest import GOLDEN_DIR
+    from oracle.golden_io import unpack_scene
+    from surf_renderer_amd import render
+    npz = np.load(os.path.join(GOLDEN_DIR, case + ".npz"), allow_pickle=False)
+    scene, kw = unpack_scene(npz), json.loads(str(npz["kwargs"]))
+    res = render(scene, device="cuda:0", shading="torch", shadow=True, **kw)
+    far = scene["camera"]["far"]
+    same = (res["nearest"].cpu().numpy() == npz["out/nearest"]) | (npz["out/depth"] > far)
+    assert same.mean() >= 0.995
+    err = np.abs(res["image"].cpu().numpy() - npz["out/image"]).max(axis=-1)
+    assert (err[same] > 3e-4).mean() <= 0.005, f"{(err[same] > 3e-4).mean():.3%} of pixels differ from the reference"

@@ -47,10 +47,34 @@ def test_tch_oracle_matches_reference_torch_backend(case):
     assert_tch_parity(got, want, scene["camera"]["far"])
 
 
+SHADOW_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "s1*.npz")))
+
+
+def load_shadow_case(name):
+    npz = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    return unpack_scene(npz), {k: npz["out/" + k] for k in ("image", "depth", "nearest")}, json.loads(str(npz["kwargs"]))
+
+
+@pytest.mark.parametrize("case", SHADOW_CASES)
+def test_shadow_oracle_matches_reference_torch_backend(case):
+    """render(shadow=True) of the reference (oracle/gen_golden_shadow.py; the reference returns the shaded image, not
+    the visibility): the oracle's image must match on every pixel whose `nearest` agrees, and the fixture must
+    really hold shadows (the unshadowed oracle image differs from it on > 20 % of the pixels)."""
+    assert len(SHADOW_CASES) >= 3
+    scene, want, kw = load_shadow_case(case)
+    got = np_oracle_tch.render(scene, shadow=True, **kw)
+    far = scene["camera"]["far"]
+    same = (got["nearest"] == want["nearest"]) | (want["depth"] > far)
+    assert same.mean() >= 0.995
+    np.testing.assert_allclose(got["image"][same], want["image"][same], atol=3e-4)
+    plain = np_oracle_tch.render(scene, **kw)
+    assert (np.abs(plain["image"] - want["image"]).max(axis=-1) > 3e-4).mean() > 0.2
+
+
 def test_shadow_rays_against_geometry():
-    """The shadow part of the oracle cannot be pinned by the reference (its shadow code needs CUDA tensors), so it is
-    checked against geometry: a unit disc at height 1 under a light at height 5 shadows the floor inside radius
-    5 / 4, and nothing else; the disc itself and the unshadowed floor see the light."""
+    """Besides the reference's own outputs above, the shadow rays against geometry: a unit disc at height 1 under a
+    light at height 5 shadows the floor inside radius 5 / 4, and nothing else; the disc itself and the unshadowed
+    floor see the light."""
     f = lambda a: np.asarray(a, dtype=np.float64)
     scene = {
         "camera": {"viewport": [0, 0, 64, 48], "fovy": float(np.deg2rad(50.0)), "focal_length": 1.0,
