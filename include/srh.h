@@ -11,7 +11,9 @@
  * Conventions
  *   - Every device buffer is allocated and freed by the caller.  The library keeps no device memory
  *     and no global state between calls; all work is enqueued on the stream that is passed in and no
- *     entry point synchronises.
+ *     entry point synchronises.  (One exception, srh_render_views: its per-view frame descriptors go
+ *     through a pinned staging buffer and a ring of four batches in constant memory that the library
+ *     owns; a call waits only if the slot it reuses is still in flight, four calls back.)
  *   - Arrays use the reference's layouts (docs/scene_description.md, numpy/renderer.py:299-358):
  *     homogeneous 4-vectors, points w = 1, directions / normals w = 0, row-major, float32 on the
  *     device; index arrays are int32.
