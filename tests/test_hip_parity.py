@@ -502,3 +502,53 @@ def test_scale_millions_of_primitives_and_an_8k_frame():
         for k in ("image", "depth", "nearest"):
             assert torch.equal(a[k], b[k]), k
         del a, b
+
+
+_SPECIAL = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-30, -1e-30, 1e20, -1e20, 1e38, 3e-39, 1.0, -1.0], dtype=np.float32)
+
+
+def _poison(rng, scene, frac):
+    """Overwrite one coordinate of a fraction of the primitives (never w) with nan / inf / huge / denormal / zero."""
+    def hit(a, cols):
+        a = np.array(a, dtype=np.float32, copy=True)
+        flat = a.reshape(a.shape[0], -1)
+        for r in np.nonzero(rng.uniform(size=flat.shape[0]) < frac)[0]:
+            flat[r, rng.choice(cols)] = rng.choice(_SPECIAL)
+        return flat.reshape(a.shape)
+    for grp in scene["objects"].values():
+        if "pos" in grp:
+            grp["pos"] = hit(grp["pos"], [0, 1, 2])
+        if "normal" in grp:
+            grp["normal"] = hit(grp["normal"], [0, 1, 2])
+        if "radius" in grp:
+            grp["radius"] = hit(grp["radius"].reshape(-1, 1), [0]).reshape(-1)
+        if "face" in grp:
+            grp["face"] = hit(grp["face"], [0, 1, 2, 4, 5, 6, 8, 9, 10])
+
+
+@pytest.mark.gpu
+def test_fuzz_non_finite_and_degenerate_primitives():
+    """Random scenes in which 2-50 % of the primitives carry a nan / inf / 1e38 / denormal / zero coordinate, radius or
+    normal component: every mode gives the all-pairs fp64 result bit for bit (nan-aware), and small ones match the
+    numpy oracle -- whose comparisons drop a nan hit exactly as `near <= t` does in the reference (numpy/renderer.py:219)."""
+    from surf_renderer_amd.scene import scene_to_numpy
+    rng = np.random.RandomState(71)
+    for it in range(60):
+        scene = _random_scene(rng)
+        _poison(rng, scene, float(rng.choice([0.02, 0.2, 0.5])))
+        ref = _render(scene, mode="exact")
+        for mode, wpt in (("fast", 0), ("binned", 1), ("binned", 4)):
+            got = _render(scene, mode=mode, waves_per_tile=wpt)
+            for k in ("nearest", "depth", "image"):
+                assert np.array_equal(got[k], ref[k], equal_nan=True), f"scene {it} {mode}/{wpt}: {k} differs"
+        W, H = scene["camera"]["viewport"][2:]
+        if W * H <= 64 * 80 and sum(len(g["material_idx"]) for g in scene["objects"].values()) <= 800:
+            with np.errstate(all="ignore"):
+                want = np_oracle.render(scene_to_numpy(scene, round_fp32=True))
+                np.testing.assert_array_equal(ref["nearest"], want["nearest"])
+                d = ref["depth"].astype(np.float64)
+                assert np.all(np.isclose(d, want["depth"], rtol=DEPTH_RTOL, atol=0) | (d == want["depth"]))
+                img = ref["image"].astype(np.float64)
+                ok = np.isclose(img, want["image"], rtol=IMAGE_RTOL, atol=IMAGE_ATOL, equal_nan=True) | \
+                    ((np.abs(want["image"]) > 3e38) & np.isinf(img))          # beyond float32 on our side
+                assert ok.all(), f"scene {it}: image differs from the oracle on {(~ok).sum()} values"
