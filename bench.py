@@ -76,12 +76,17 @@ def parse():
                          "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
                          "auto = on (rehearsed with --as-rank against per-frame graph replays, which multi-GPU runs "
                          "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
-    ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced"],
+    ap.add_argument("--owner-frac", type=float, default=0.875,
+                    help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it")
+    ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner"],
                     help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
                          "g and P+g of 2P, so that a scene that is densest in the middle loads every rank alike.  "
                          "auto = contiguous: rehearsed with --as-rank, the balanced form evens the ranks out (26-40 us "
                          "instead of 9-34 us at P = 8) but its doubled per-view fixed work makes the slowest rank "
-                         "slower (40 vs 34 us at P = 8, 59 vs 56 at P = 4)")
+                         "slower (40 vs 34 us at P = 8, 59 vs 56 at P = 4).  owner = owner-weighted slabs "
+                         "(dist.owner_slabs): the rank that assembles a frame renders --owner-frac of it, so that less "
+                         "of the frame crosses the xGMI links; auto picks it at 2 ranks, where an equal split is bound "
+                         "four times over by the single link between the two GPUs")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -142,7 +147,8 @@ def main():
             dist.init_process_group(backend)
 
     from surf_renderer_amd import _lib, renderer, synthetic
-    from surf_renderer_amd.dist import FrameBatcher, balanced_slabs, exchange_frames, gather_rows, row_slab
+    from surf_renderer_amd.dist import (FrameBatcher, balanced_slabs, exchange_frames, exchange_frames_uneven, gather_rows,
+                                        owner_slabs, row_slab)
 
     W, H, M = args.width, args.height, args.prims
     scene = synthetic.disk_cloud_scene(M, W, H)          # same seed on every rank -> identical replicas
@@ -193,11 +199,43 @@ def main():
     # concatenation, in rank order, of [half-slab g | half-slab P+g])
     balanced = batched and not args.as_rank and args.slabs == "balanced" and H % (2 * world) == 0
     pieces = balanced_slabs(H, rank, world) if balanced else [(r0, r1)]
+    # owner-weighted slabs (batched collection only): my rows of the frame that rank k assembles differ per k
+    owner = batched and not args.as_rank and world > 1 and \
+        (args.slabs == "owner" or (args.slabs == "auto" and world == 2))
+    if owner:
+        # pre-flight of the unequal-split exchange; if this stack cannot do it, every rank keeps the equal slabs
+        ok = torch.ones(1, device=device)
+        try:
+            sr = [3 if k == rank else 1 for k in range(world)]
+            src = torch.cat([torch.full((sr[k], 4), 100.0 * rank + k, device=device) for k in range(world)])
+            dst = torch.empty((sum(sr), 4), dtype=torch.float32, device=device)
+            exchange_frames_uneven(src, dst, sr, sr)
+            torch.cuda.synchronize(device)
+            want = torch.cat([torch.full((sr[g], 4), 100.0 * g + rank, device=device) for g in range(world)])
+            if not torch.equal(dst, want):
+                ok.zero_()
+        except Exception as exc:                          # noqa: BLE001
+            print(f"[bench] rank {rank}: unequal all-to-all pre-flight failed ({exc!r})", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if rank == 0:
+                print("[bench] unequal-split exchange unavailable: equal slabs", file=sys.stderr)
+            owner = False
+    if owner:
+        rows_all = owner_slabs(H, world, args.owner_frac)
+        my_rows = [rows_all[k][rank] for k in range(world)]
+        send_rows = [b_ - a for a, b_ in my_rows]
+        recv_rows = [b_ - a for a, b_ in rows_all[rank]]
+        pieces = [my_rows[rank]]                   # the launch the event pairs bracket: my own frame's tall slab
     main = torch.cuda.current_stream(device)
     # the render kernel's own duration (roofline) comes from event pairs around it on every `ev_every`-th timed
     # step; those steps launch eagerly, the others replay graphs
     ev_every = 1 if args.graph == "off" else 8
-    if batched and args.batch_call != "off":
+    if owner:
+        # frames go out one library call each; every 4th batch the tall slab (my own frame's) carries the event pair
+        events = [_lib.EventPair() if (i % world == rank and (i // world) % 4 == 0) else None for i in range(args.steps)]
+    elif batched and args.batch_call != "off":
         # whole batches are one library call; every 8th batch is rendered frame by frame with the events
         events = [_lib.EventPair() if (i // world) % 8 == 0 else None for i in range(args.steps)]
     else:
@@ -243,7 +281,35 @@ def main():
         return (slab.as_strided((hh, W, 3), (4 * W, 3, 1), slab.storage_offset()),
                 slab.as_strided((hh, W), (4 * W, 1), slab.storage_offset() + 3 * W))
 
-    if batched:
+    if batched and owner:
+        n_bat = 2
+
+        def render_slot(i, slot, ev):
+            k = i % world
+            enqueue((i // world % n_bat, k, 0), streams[k % n_str], *views(slot), scratch[k % n_str], ev, rows=my_rows[k])
+
+        def before_exchange():
+            for s_ in streams:
+                main.wait_stream(s_)               # every slab of the batch is rendered
+
+        def after_reuse_wait():
+            for s_ in streams:
+                s_.wait_stream(main)               # main waited for the exchange that used this buffer
+
+        batcher = FrameBatcher(world, (0, 4 * W), torch.float32, device, render_slot, before_exchange,
+                               after_reuse_wait, n_batches=n_bat, send_rows=send_rows, recv_rows=recv_rows)
+        send, recv = batcher.send, batcher.recv
+
+        def step(ev=None):
+            batcher.submit(ev)
+            counter[0] += 1
+
+        def fence():
+            batcher.flush()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            torch.cuda.synchronize(device)
+    elif batched:
         n_bat = 2
 
         def render_slot(i, slot, ev):
@@ -380,7 +446,7 @@ def main():
             torch.cuda.synchronize(device)
 
     # capture every output slot's graph up front, before any collective is in flight
-    if graph_state["on"]:
+    if graph_state["on"] and not owner:
         if batched:
             for b in range(n_bat):
                 for k in range(world):
@@ -406,7 +472,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if args.check:
+    if args.check and owner:
+        ref = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
+        renderer.render_buffers(buf, cam, rows=(0, H), mode=args.mode, out=(*views(ref), None))
+        torch.cuda.synchronize(device)
+        rendered = args.warmup + args.steps
+        got = [recv[b] for b in range(n_bat)
+               if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
+        for t in got:                                  # the whole frame assembled on this rank, every rank's rows
+            if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
+                raise SystemExit(f"[bench] rank {rank}: an assembled frame differs from the eager full-frame render")
+        if rank == 0:
+            print(f"[bench] check ok: {len(got)} assembled frame(s) equal the eager full-frame render", file=sys.stderr)
+    elif args.check:
         ref = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
         at = 0
         for a, b_ in pieces:
@@ -460,10 +538,12 @@ def main():
                        "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
-                                    if batched and args.batch_call != "off" else "per frame"),
-                       "rows_per_rank": ("two half-slabs, g and P+g of 2P" if balanced else "one contiguous slab"),
+                                    if batched and not owner and args.batch_call != "off" else "per frame"),
+                       "rows_per_rank": (f"owner-weighted: the rank that assembles a frame renders {max(recv_rows)} of "
+                                         f"its {H} rows, the others {min(recv_rows)} each" if owner else
+                                         "two half-slabs, g and P+g of 2P" if balanced else "one contiguous slab"),
                        "collection": "none" if (not use_dist or frames_par) else
-                                     (f"all-to-all per {world} frames, frame k on rank k" if batched
+                                     (f"all-to-all per {world} frames{' (unequal splits)' if owner else ''}, frame k on rank k" if batched
                                       else "gather to rank 0 per frame")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,

@@ -40,6 +40,33 @@ def all_slabs(height: int, world: int) -> List[Tuple[int, int]]:
     return [row_slab(height, g, world) for g in range(world)]
 
 
+def owner_slabs(height: int, world: int, owner_frac: float, granule: int = 16) -> List[List[Tuple[int, int]]]:
+    """Owner-weighted row partition for the batched collection: ``rows[k][g]`` = the rows rank g renders of the frame
+    that rank k assembles.  The owner takes about ``owner_frac`` of the frame, the others share the rest equally; the
+    slabs of one frame are contiguous, in rank order, and sized in multiples of ``granule`` rows (the tile height).
+    With rotating owners every rank still renders one frame's worth of rows per batch of P frames, but only
+    (1 - owner_frac) / (P - 1) of a frame crosses each xGMI link -- at P = 2 an equal split is bound by the one link
+    between the two GPUs, four times over."""
+    if world < 2:
+        return [[(0, height)]]
+    if not (1.0 / world <= owner_frac < 1.0):
+        raise ValueError(f"owner_frac must be in [1/P, 1), got {owner_frac}")
+    small = int((1.0 - owner_frac) * height / (world - 1)) // granule * granule
+    small = max(small, min(granule, height // world))
+    big = height - (world - 1) * small
+    if big < small or small < 1:
+        raise ValueError(f"cannot split {height} rows over {world} ranks with owner_frac {owner_frac}")
+    rows = []
+    for k in range(world):
+        at, frame = 0, []
+        for g in range(world):
+            n = big if g == k else small
+            frame.append((at, at + n))
+            at += n
+        rows.append(frame)
+    return rows
+
+
 class GatherHandle:
     """Completion handle of one frame's gather (possibly several point-to-point requests)."""
 
@@ -125,6 +152,43 @@ def exchange_frames(send: torch.Tensor, recv: torch.Tensor, group: Optional[dist
     return handle
 
 
+def exchange_frames_uneven(send: torch.Tensor, recv: torch.Tensor, send_rows: List[int], recv_rows: List[int],
+                           group: Optional[dist.ProcessGroup] = None, async_op: bool = False) -> GatherHandle:
+    """``exchange_frames`` for slabs of different heights (``owner_slabs``): ``send`` (sum(send_rows), ...) holds this
+    rank's slab of frame k at rows [sum(send_rows[:k]), +send_rows[k]); on return ``recv`` (sum(recv_rows), ...) holds
+    the slab of every rank g of THIS rank's frame at [sum(recv_rows[:g]), +recv_rows[g]) -- i.e. the assembled frame.
+    NCCL/RCCL: one ``all_to_all_single`` with split sizes; other backends: one batched send/recv group."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if len(send_rows) != world or len(recv_rows) != world:
+        raise ValueError("send_rows / recv_rows need one entry per rank")
+    if send.shape[0] != sum(send_rows) or recv.shape[0] != sum(recv_rows) or send.shape[1:] != recv.shape[1:]:
+        raise ValueError(f"buffers {tuple(send.shape)} / {tuple(recv.shape)} do not match the row counts")
+    if not (send.is_contiguous() and recv.is_contiguous()):
+        raise ValueError("send and recv must be contiguous")
+    if send_rows[rank] != recv_rows[rank]:
+        raise ValueError("a rank's own slab must have the same height on both sides")
+    s_at = [sum(send_rows[:k]) for k in range(world)]
+    r_at = [sum(recv_rows[:g]) for g in range(world)]
+    if world == 1:
+        recv.copy_(send)
+        return GatherHandle()
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_to_all_single(recv, send, output_split_sizes=list(recv_rows), input_split_sizes=list(send_rows),
+                                      group=group, async_op=async_op)
+        return GatherHandle([work] if async_op else [])
+    recv[r_at[rank]:r_at[rank] + recv_rows[rank]].copy_(send[s_at[rank]:s_at[rank] + send_rows[rank]])
+    ops = []
+    for g in range(world):
+        if g != rank:
+            ops.append(dist.P2POp(dist.isend, send[s_at[g]:s_at[g] + send_rows[g]], g, group))
+            ops.append(dist.P2POp(dist.irecv, recv[r_at[g]:r_at[g] + recv_rows[g]], g, group))
+    handle = GatherHandle(dist.batch_isend_irecv(ops))
+    if not async_op:
+        handle.wait()
+    return handle
+
+
 class FrameBatcher:
     """Scheduling of the batched collection: frames are rendered into `send[b][k]` (b = batch buffer, k = frame within
     the batch of P = world frames), a full batch is exchanged (`exchange_frames`) so that frame k lands on rank k, and a
@@ -138,10 +202,21 @@ class FrameBatcher:
     `frame(b)` is the receive buffer of batch buffer b: on rank k it holds frame (batch * P + k), slab g at [g]."""
 
     def __init__(self, world: int, slab_shape, dtype, device, render, before_exchange=None, after_reuse_wait=None,
-                 n_batches: int = 2, group: Optional[dist.ProcessGroup] = None):
+                 n_batches: int = 2, group: Optional[dist.ProcessGroup] = None,
+                 send_rows: Optional[List[int]] = None, recv_rows: Optional[List[int]] = None):
+        """With ``send_rows`` / ``recv_rows`` (``owner_slabs``: this rank's slab height per frame of a batch, and every
+        rank's slab height of this rank's own frame) the buffers are flat -- send (sum(send_rows), *slab_shape[1:]),
+        recv (H, ...) = the assembled frame -- and slot k is rows [sum(send_rows[:k]), +send_rows[k]) of send."""
         self.world, self.group, self.n_batches = world, group, n_batches
-        self.send = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
-        self.recv = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
+        self.send_rows, self.recv_rows = send_rows, recv_rows
+        if send_rows is None:
+            self.send = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
+            self.recv = [torch.empty((world, *slab_shape), dtype=dtype, device=device) for _ in range(n_batches)]
+        else:
+            tail = tuple(slab_shape[1:])
+            self.send = [torch.empty((sum(send_rows), *tail), dtype=dtype, device=device) for _ in range(n_batches)]
+            self.recv = [torch.empty((sum(recv_rows), *tail), dtype=dtype, device=device) for _ in range(n_batches)]
+            self._send_at = [sum(send_rows[:k]) for k in range(world)]
         self.pending: List[Optional[GatherHandle]] = [None] * n_batches
         self.delivered: List[int] = [-1] * n_batches          # index of the batch each receive buffer holds
         self._render, self._before, self._after = render, before_exchange, after_reuse_wait
@@ -149,6 +224,12 @@ class FrameBatcher:
 
     def slot(self, i: int) -> Tuple[int, int]:
         return (i // self.world) % self.n_batches, i % self.world
+
+    def slot_view(self, b: int, k: int) -> torch.Tensor:
+        """The part of send buffer b that takes this rank's slab of frame k of a batch."""
+        if self.send_rows is None:
+            return self.send[b][k]
+        return self.send[b][self._send_at[k]:self._send_at[k] + self.send_rows[k]]
 
     def submit(self, *render_args) -> None:
         """Render the next frame; exchange its batch when it is the last of it."""
@@ -160,7 +241,7 @@ class FrameBatcher:
             self.pending[b] = None
             if self._after:
                 self._after()
-        self._render(i, self.send[b][k], *render_args)
+        self._render(i, self.slot_view(b, k), *render_args)
         if k == self.world - 1:
             self._exchange(b, i // self.world)
 
@@ -183,7 +264,11 @@ class FrameBatcher:
     def _exchange(self, b: int, batch_index: int) -> None:
         if self._before:
             self._before()
-        self.pending[b] = exchange_frames(self.send[b], self.recv[b], group=self.group, async_op=True)
+        if self.send_rows is None:
+            self.pending[b] = exchange_frames(self.send[b], self.recv[b], group=self.group, async_op=True)
+        else:
+            self.pending[b] = exchange_frames_uneven(self.send[b], self.recv[b], self.send_rows, self.recv_rows,
+                                                     group=self.group, async_op=True)
         self.delivered[b] = batch_index
 
     def flush(self) -> None:

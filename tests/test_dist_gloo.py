@@ -192,3 +192,74 @@ def test_balanced_slabs_partition_the_image():
         assert sorted(rows) == list(range(height))
     with pytest.raises(ValueError):
         balanced_slabs(100, 0, 8)
+
+
+def test_owner_slabs_partition_every_frame():
+    from surf_renderer_amd.dist import owner_slabs
+    for height, world, frac in ((2048, 2, 0.875), (2048, 4, 0.4), (96, 3, 0.5), (2048, 8, 0.125), (48, 2, 0.9)):
+        rows = owner_slabs(height, world, frac)
+        assert len(rows) == world
+        per_rank = [0] * world
+        for k, frame in enumerate(rows):
+            assert frame[0][0] == 0 and frame[-1][1] == height
+            for (a0, a1), (b0, b1) in zip(frame, frame[1:]):
+                assert a1 == b0
+            sizes = [b - a for a, b in frame]
+            assert sizes[k] == max(sizes) and len({s for g, s in enumerate(sizes) if g != k}) == 1
+            for g, s in enumerate(sizes):
+                per_rank[g] += s
+        assert len(set(per_rank)) == 1 and per_rank[0] == height      # every rank renders one frame's worth per batch
+    assert owner_slabs(2048, 2, 0.875)[0] == [(0, 1792), (1792, 2048)]
+    assert owner_slabs(2048, 2, 0.875)[1] == [(0, 256), (256, 2048)]
+    with pytest.raises(ValueError):
+        owner_slabs(64, 2, 0.2)
+
+
+def _owner_worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from surf_renderer_amd.dist import FrameBatcher, owner_slabs
+        height, w = 64, 3
+        rows = owner_slabs(height, world, 0.75)
+        send_rows = [rows[k][rank][1] - rows[k][rank][0] for k in range(world)]
+        recv_rows = [rows[rank][g][1] - rows[rank][g][0] for g in range(world)]
+
+        def render(i, slot):
+            a, b = rows[i % world][rank]
+            assert slot.shape[0] == b - a
+            # every row carries frame number and absolute row index: the assembled frame is then checkable row by row
+            slot.copy_((1000.0 * i + torch.arange(a, b, dtype=torch.float32))[:, None].expand(b - a, w))
+
+        fb = FrameBatcher(world, (0, w), torch.float32, "cpu", render, send_rows=send_rows, recv_rows=recv_rows)
+        for _ in range(n_frames):
+            fb.submit()
+        fb.flush()
+        ok = True
+        for b in range(fb.n_batches):
+            batch = fb.delivered[b]
+            if batch < 0:
+                continue
+            frame = batch * world + rank
+            if frame >= n_frames:
+                continue
+            want = (1000.0 * frame + torch.arange(height, dtype=torch.float32))[:, None].expand(height, w)
+            ok = ok and bool(torch.equal(fb.frame(b), want))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 6), (3, 9), (2, 5)])
+def test_owner_weighted_batches_assemble_whole_frames(world, n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(world))
+    assert all(results.values()), results
