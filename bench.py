@@ -76,7 +76,7 @@ def parse():
                          "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
                          "auto = on (rehearsed with --as-rank against per-frame graph replays, which multi-GPU runs "
                          "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
-    ap.add_argument("--owner-frac", type=float, default=0.875,
+    ap.add_argument("--owner-frac", type=float, default=0.9375,
                     help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it")
     ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner"],
                     help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
