@@ -76,8 +76,9 @@ def parse():
                          "library call (srh_render_views: every kernel launched once per batch) instead of P calls; "
                          "auto = on (rehearsed with --as-rank against per-frame graph replays, which multi-GPU runs "
                          "cannot use: 34 vs 45 us per frame at P = 8, 56 vs 57 at P = 4, 73 vs 71 at P = 2)")
-    ap.add_argument("--owner-frac", type=float, default=0.9375,
-                    help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it")
+    ap.add_argument("--owner-frac", type=float, default=0.0,
+                    help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it; "
+                         "0 = the others render 128 rows each (0.9375 at 2 ranks, 0.8125 at 4 for 2048 rows)")
     ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner"],
                     help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
                          "g and P+g of 2P, so that a scene that is densest in the middle loads every rank alike.  "
@@ -85,8 +86,8 @@ def parse():
                          "instead of 9-34 us at P = 8) but its doubled per-view fixed work makes the slowest rank "
                          "slower (40 vs 34 us at P = 8, 59 vs 56 at P = 4).  owner = owner-weighted slabs "
                          "(dist.owner_slabs): the rank that assembles a frame renders --owner-frac of it, so that less "
-                         "of the frame crosses the xGMI links; auto picks it at 2 ranks, where an equal split is bound "
-                         "four times over by the single link between the two GPUs")
+                         "of the frame crosses the xGMI links; auto picks it at 2 and 4 ranks, where an equal split is "
+                         "bound by the links (four times over at 2 ranks) and the middle slabs are the busiest")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
@@ -201,7 +202,7 @@ def main():
     pieces = balanced_slabs(H, rank, world) if balanced else [(r0, r1)]
     # owner-weighted slabs (batched collection only): my rows of the frame that rank k assembles differ per k
     owner = batched and not args.as_rank and world > 1 and \
-        (args.slabs == "owner" or (args.slabs == "auto" and world == 2))
+        (args.slabs == "owner" or (args.slabs == "auto" and world <= 4 and H >= 256 * world))
     if owner:
         # pre-flight of the unequal-split exchange; if this stack cannot do it, every rank keeps the equal slabs
         ok = torch.ones(1, device=device)
@@ -223,7 +224,8 @@ def main():
                 print("[bench] unequal-split exchange unavailable: equal slabs", file=sys.stderr)
             owner = False
     if owner:
-        rows_all = owner_slabs(H, world, args.owner_frac)
+        owner_frac = args.owner_frac if args.owner_frac > 0 else 1.0 - (world - 1) * min(128, H // (2 * world)) / H
+        rows_all = owner_slabs(H, world, owner_frac)
         my_rows = [rows_all[k][rank] for k in range(world)]
         send_rows = [b_ - a for a, b_ in my_rows]
         recv_rows = [b_ - a for a, b_ in rows_all[rank]]
