@@ -80,7 +80,7 @@ def parse():
                     help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it; "
                          "0 = the others render 128 rows each (0.9375 at 2 ranks, 0.8125 at 4 for 2048 rows)")
     ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner"],
-                    help="rows of a rank: one contiguous slab, or (batched collection, H % 2P == 0) two half-slabs, "
+                    help="rows of a rank: one contiguous slab, or (batched collection, H %% 2P == 0) two half-slabs, "
                          "g and P+g of 2P, so that a scene that is densest in the middle loads every rank alike.  "
                          "auto = contiguous: rehearsed with --as-rank, the balanced form evens the ranks out (26-40 us "
                          "instead of 9-34 us at P = 8) but its doubled per-view fixed work makes the slowest rank "
