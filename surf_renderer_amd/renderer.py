@@ -558,6 +558,14 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     ``streams`` HIP streams.  All
     cameras must share one viewport size.  Returns stacked tensors ``image`` (B,H,W,3), ``depth`` (B,H,W) and
     ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` / ``use_quartic`` as in ``render``.  Forward only."""
+    unknown = set(shading_kw) - {"shading", "double_sided", "use_quartic", "waves_per_tile"}
+    if "shadow" in unknown and shading_kw["shadow"]:
+        raise ValueError("render_views does not run the shadow-ray pass; call render(scene, shading='torch', "
+                         "shadow=True) per view")
+    unknown.discard("shadow")
+    if unknown:
+        raise TypeError(f"render_views() got unexpected keyword arguments {sorted(unknown)}")
+    shading_kw.pop("shadow", None)
     device = torch.device(device)
     buf = flatten_scene(scene, device)
     cams = [camera_struct(c, shading_kw.get("shading", "numpy")) for c in cameras]

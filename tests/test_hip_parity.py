@@ -552,3 +552,17 @@ def test_fuzz_non_finite_and_degenerate_primitives():
                 ok = np.isclose(img, want["image"], rtol=IMAGE_RTOL, atol=IMAGE_ATOL, equal_nan=True) | \
                     ((np.abs(want["image"]) > 3e38) & np.isinf(img))          # beyond float32 on our side
                 assert ok.all(), f"scene {it}: image differs from the oracle on {(~ok).sum()} values"
+
+
+@pytest.mark.gpu
+def test_render_views_refuses_what_it_cannot_do():
+    from surf_renderer_amd import render_views, synthetic
+    scene = synthetic.demo_scene(32, 24)
+    cams = [scene["camera"]]
+    with pytest.raises(ValueError, match="shadow"):
+        render_views(scene, cams, device="cuda:0", shading="torch", shadow=True)
+    with pytest.raises(TypeError, match="unexpected"):
+        render_views(scene, cams, device="cuda:0", tile_size=4096)
+    with pytest.raises(Exception, match="perspective cameras only"):
+        render_views(scene, [dict(scene["camera"], proj_type="ortho")], device="cuda:0", shading="torch")
+    assert render_views(scene, cams, device="cuda:0", shadow=False)["image"].shape == (1, 24, 32, 3)
