@@ -33,15 +33,26 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # fp32 vector peak it prices them against
 FLOP_PER_DISK_TEST = 17
 VALU_F32_PEAK_TFLOPS = 157.3
-# What actually bounds the render kernel is vector-instruction issue.  Its loops are VOP3-class instructions (fma,
-# med3, bfi, packed f32, fp64), which a SIMD issues at one wave-instruction per 4 cycles whatever the number of
-# waves (tools/ubench_valu.hip: 1.75-1.85 ns; only plain add/mul/logic reach 2 cycles): 1024 SIMDs x 2.4 GHz / 4.
+# What actually bounds the render kernel is vector-instruction issue: tools/ubench_issue.hip (output committed as
+# profiles/r02_ubench_issue.txt) gives the cycles per wave-instruction per SIMD for every instruction class the kernel
+# uses; the peak below is the rate of its dominant class.
 VALU_PEAK_GINSTR_S = 614.4
-# SQ_INSTS_VALU of one render launch of the default workload (profiles/r01_f_pmc_counters.txt)
-VALU_WAVE_INSTR_PER_LAUNCH = 49.2e6
-# HBM bytes of one render launch of the default workload from the PMC counters (same file): WRITE_SIZE 70 984 KiB +
-# FETCH_SIZE 18 014 KiB x 2 (the guide's gfx950 correction for the read side, worst case)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = (70984 + 2 * 18014) * 1024.0
+PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
+
+
+def load_pmc():
+    """Per-launch PMC counters of the render kernel on the default workload, as collected by tools/collect_pmc.py and
+    committed under profiles/ together with the commit and the library hash they were taken at.  None when absent."""
+    try:
+        with open(PMC_FILE) as fh:
+            d = json.load(fh)
+        k = d["kernels"]["k_render_binned"]
+        return {"commit": d.get("commit"), "lib_sha256": d.get("lib_sha256"),
+                # HBM bytes: WRITE_SIZE + 2 x FETCH_SIZE (KiB units; the guide's gfx950 correction for the read side)
+                "traffic_bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0,
+                "valu_wave_instr": float(k["SQ_INSTS_VALU"])}
+    except Exception:                                       # noqa: BLE001 -- no file, no constants
+        return None
 
 
 def parse():
@@ -91,9 +102,14 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: create the RCCL process group and use the multi-GPU frame collection even with "
                          "one rank (exercises the collective, stream and graph plumbing on a one-GPU box)")
-    ap.add_argument("--check", action="store_true",
-                    help="after the timed loop compare the last collected frame on this rank with a fresh eager render "
-                         "of the same rows (stream / graph / collective ordering self-test)")
+    ap.add_argument("--check", dest="check", action="store_true", default=True,
+                    help="(default) after the timed loop compare every output slot / collected frame on this rank, bit "
+                         "for bit, with a fresh eager render of the same rows and exit non-zero on a mismatch (stream / "
+                         "graph / collective ordering self-test; outside the timed region)")
+    ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--warmup-ms", type=float, default=150.0,
+                    help="after the --warmup steps keep submitting untimed frames until this much wall time has passed "
+                         "since the first warm-up frame, so that a short run is timed at ramped clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pixels", type=int, default=4096, help="pixels in the CPU-baseline sample (about 14 s of numpy)")
     return ap.parse_args()
@@ -243,12 +259,18 @@ def main():
     else:
         events = [_lib.EventPair() if i % ev_every == 0 else None for i in range(args.steps)]
     counter = [0]
+    pipe = None
 
     graphs = {}
     # Graph replay is used on the single-process path only.  With a process group alive (RCCL kernels and device copies
     # running beside the replays) the one-rank rehearsal `--force-dist --graph on` ended in a GPU memory fault on
     # ROCm 7.2, while the same schedule with eager launches runs clean; multi-GPU runs therefore launch eagerly.
     graph_state = {"on": args.graph == "on" or (args.graph == "auto" and not use_dist), "captured": 0}
+    if graph_state["on"] and use_dist and not os.environ.get("SRH_BENCH_GRAPH_WITH_PG"):
+        # see DESIGN.md section 5: until that fault has a named cause this combination does not run
+        raise SystemExit("[bench] --graph on with a live process group is refused: this combination ended in a GPU "
+                         "memory fault in the round-1 rehearsal (DESIGN.md section 5).  SRH_BENCH_GRAPH_WITH_PG=1 "
+                         "overrides, for the diagnostic run only.")
 
     def enqueue(key, stream, image, depth, ws, ev, rows=None):
         """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,
@@ -410,13 +432,29 @@ def main():
         def fence():
             torch.cuda.synchronize(device)
         n_buf, slabs = 0, []
+    elif not use_dist:
+        # single process: surf_renderer_amd.pipeline.FramePipeline (the same object tests/test_hip_pipeline.py checks)
+        from surf_renderer_amd.pipeline import FramePipeline
+        pipe = FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
+                             strict_graphs=args.graph == "on")
+        graph_state["on"] = pipe.use_graphs
+        graph_state["captured"] = pipe.captured
+        n_buf, slabs = n_str, pipe.slabs
+
+        def step(ev=None):
+            counter[0] += 1
+            pipe.submit(ev)
+
+        def fence():
+            pipe.sync()
+            torch.cuda.synchronize(device)
     else:
         n_buf = n_str
         frames, slabs = [], []
         for _ in range(n_buf):
             if rank == 0 or frames_par:
                 frame = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
-                slab = frame[r0:r1] if not args.as_rank else torch.empty((h, 4 * W), dtype=torch.float32, device=device)
+                slab = frame[r0:r1]
             else:
                 frame = None
                 slab = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
@@ -433,7 +471,7 @@ def main():
                 pending[b] = None
             image, depth = views(slabs[b])
             enqueue((b,), streams[b], image, depth, scratch[b], ev)
-            if use_dist and not frames_par:
+            if not frames_par:
                 with torch.cuda.stream(streams[b]):
                     pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
 
@@ -443,12 +481,12 @@ def main():
                     pending[b].wait()
                     pending[b] = None
             torch.cuda.synchronize(device)
-            if use_dist:
-                dist.barrier()
+            dist.barrier()
             torch.cuda.synchronize(device)
 
-    # capture every output slot's graph up front, before any collective is in flight
-    if graph_state["on"] and not owner:
+    # capture every output slot's graph up front, before any collective is in flight (the single-process pipeline
+    # has captured its own)
+    if graph_state["on"] and use_dist and not owner:
         if batched:
             for b in range(n_bat):
                 for k in range(world):
@@ -461,9 +499,36 @@ def main():
             for b in range(n_buf):
                 enqueue((b,), streams[b], *views(slabs[b]), scratch[b], None)
         torch.cuda.synchronize(device)
+    # Warm-up: the --warmup steps, then more untimed frames until --warmup-ms of wall time have passed since the first
+    # one -- a handful of 0.1 ms frames does not bring the clocks up, and the timed region of a short run would then
+    # be measured on a cold GPU.  Every rank runs the same number of extra frames (they contain collectives).
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
     fence()
+    warm_steps = args.warmup
+    spent = time.perf_counter() - t_w
+    if use_dist:
+        t = torch.tensor([spent], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        spent = float(t.item())
+    left = args.warmup_ms * 1e-3 - spent
+    if left > 0:
+        per = max(spent / max(args.warmup, 1), 2e-5) if args.warmup > 0 else 2e-4
+        chunk = max(world, 32) // world * world                 # whole batches
+        extra = int(min(max(left / per, chunk), 20000)) // chunk * chunk
+        done = 0
+        while done < extra:
+            for _ in range(chunk):
+                step()
+            done += chunk
+            fence()
+            if not use_dist and time.perf_counter() - t_w >= args.warmup_ms * 1e-3:
+                break                                           # single process: stop on the clock
+        warm_steps += done
+    warm_ms = 1e3 * (time.perf_counter() - t_w)
+    if pipe is not None:
+        pipe.poison()                                           # the check below then proves the timed frames wrote their slabs
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(events[i])
@@ -474,6 +539,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    check_note = None
     if args.check and owner:
         ref = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
         renderer.render_buffers(buf, cam, rows=(0, H), mode=args.mode, out=(*views(ref), None))
@@ -484,9 +550,17 @@ def main():
         for t in got:                                  # the whole frame assembled on this rank, every rank's rows
             if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
                 raise SystemExit(f"[bench] rank {rank}: an assembled frame differs from the eager full-frame render")
+        check_note = f"{len(got)} assembled frame(s) equal the eager full-frame render bit for bit"
         if rank == 0:
-            print(f"[bench] check ok: {len(got)} assembled frame(s) equal the eager full-frame render", file=sys.stderr)
-    elif args.check:
+            print(f"[bench] check ok: {check_note}", file=sys.stderr)
+    elif args.check and pipe is not None:
+        try:
+            n_ok = pipe.verify()
+        except RuntimeError as exc:
+            raise SystemExit(f"[bench] check FAILED: {exc}")
+        check_note = f"{n_ok} output slab(s) of the timed frames equal an eager render bit for bit"
+        print(f"[bench] check ok: {check_note}", file=sys.stderr)
+    elif args.check and use_dist:
         ref = torch.empty((h, 4 * W), dtype=torch.float32, device=device)
         at = 0
         for a, b_ in pieces:
@@ -502,8 +576,9 @@ def main():
         for t in got:
             if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
                 raise SystemExit(f"[bench] rank {rank}: a collected frame differs from the eager render")
+        check_note = f"{len(got)} collected slab(s) equal the eager render bit for bit"
         if rank == 0:
-            print(f"[bench] check ok: {len(got)} collected slab(s) equal the eager render", file=sys.stderr)
+            print(f"[bench] check ok: {check_note}", file=sys.stderr)
 
     timed = [e for e in events if e is not None and (not args.as_rank or args.batch_call != "on")]
     kernel_ms = float(np.mean([e.elapsed_ms() for e in timed])) if timed else 0.0
@@ -521,7 +596,9 @@ def main():
         ach_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned") \
             and not args.as_rank
-        ginstr_s = VALU_WAVE_INSTR_PER_LAUNCH / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        pmc = load_pmc() if default_workload else None
+        valu_n = pmc["valu_wave_instr"] if pmc else 0.0
+        ginstr_s = valu_n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "frames/s + Gray-prim tests/s, 2048² × 100k disk splats, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "gtests_per_s": fps * tests / 1e9,
@@ -535,8 +612,10 @@ def main():
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
                        "frames_in_flight": n_str,
-                       "launch": f"hipGraph replay ({graph_state['captured']} graphs)" if graph_state["on"] and graphs
-                                 else "eager",
+                       "launch": f"hipGraph replay ({graph_state['captured']} graphs)"
+                                 if graph_state["on"] and graph_state["captured"] else "eager",
+                       "warmup_steps_run": warm_steps, "warmup_ms_run": warm_ms,
+                       "check": check_note if args.check else "off",
                        "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
@@ -549,9 +628,10 @@ def main():
                                       else "gather to rank 0 per frame")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None,
-                         "traffic_source": "profiles/r01_f_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "separate passes), constant" if default_workload else None,
+                         "traffic": pmc["traffic_bytes"] if pmc else None,
+                         "traffic_source": (f"profiles/r02_pmc.json: rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (separate "
+                                            f"passes, per launch), taken at commit {pmc['commit']}, libsrh.so sha256 "
+                                            f"{str(pmc['lib_sha256'])[:12]}; not re-measured by this run") if pmc else None,
                          "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes,
                          # `kernel_ms` is one launch's duration WHILE `concurrent_launches` frames share the GPU (their
@@ -568,10 +648,11 @@ def main():
                                  "flop_per_test": FLOP_PER_DISK_TEST},
             "valu_issue": ({"achieved": ginstr_s, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
                             "frac": ginstr_s / VALU_PEAK_GINSTR_S,
-                            "frac_per_job_time": VALU_WAVE_INSTR_PER_LAUNCH / (elapsed / args.steps) / 1e9 / VALU_PEAK_GINSTR_S,
-                            "wave_instr_per_launch": VALU_WAVE_INSTR_PER_LAUNCH,
-                            "source": "SQ_INSTS_VALU (profiles/) over the live kernel time; peak = one VOP3-class "
-                                      "instruction per SIMD per 4 cycles"} if default_workload else None),
+                            "frac_per_job_time": valu_n / (elapsed / args.steps) / 1e9 / VALU_PEAK_GINSTR_S,
+                            "wave_instr_per_launch": valu_n,
+                            "source": f"SQ_INSTS_VALU from profiles/r02_pmc.json (commit {pmc['commit']}) over the live "
+                                      "kernel time; peak = one wave-instruction per SIMD per 4 cycles, the measured issue "
+                                      "cost of the kernel's instruction mix (profiles/r02_ubench_issue.txt)"} if pmc else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)

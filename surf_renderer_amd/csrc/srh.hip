@@ -735,24 +735,37 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   // orthographic frames take the all-pairs fp64 kernel of their own, whatever mode is asked for
   const int mode = F.ortho ? SRH_MODE_EXACT : (params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode);
   hipStream_t st = (hipStream_t)stream;
-  if (mode == SRH_MODE_BINNED) {
-    setup_binning(F, L, workspace);
+#ifdef SRH_ABL_RENDERONLY   // diagnostic build: after the first 16 calls only the render kernel runs (bins are reused)
+  static int abl_calls = 0;
+  const bool abl_skip_binning = ++abl_calls > 16;
+#else
+  const bool abl_skip_binning = false;
+#endif
+#ifdef SRH_ABL_BINONLY      // diagnostic build: after the first 16 calls the render kernel is skipped
+  static int abl_calls2 = 0;
+  const bool abl_skip_render = ++abl_calls2 > 16;
+#else
+  const bool abl_skip_render = false;
+#endif
+  if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
+  if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
     hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);
     if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
   }
 
-  for (int s = 0; s < F.nseg; ++s) {
+  for (int s = 0; s < F.nseg && !abl_skip_binning; ++s) {
     const SegDev& S = F.seg[s];
     hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64,
                        (float*)S.rec32);
   }
-  if (mode == SRH_MODE_BINNED) {
+  if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
     hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + 255) / 256)), dim3(256), 0, st, F);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
     hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + 255) / 256)), dim3(256), 0, st, F);
   }
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
-  if (mode == SRH_MODE_BINNED) {
+  if (abl_skip_render) {
+  } else if (mode == SRH_MODE_BINNED) {
     const unsigned groups = binned_grid(F);   // whole regions of tiles, a multiple of 8 of them (see k_render_binned)
     // one wave per tile while that still gives every SIMD several waves; four waves per tile for small frames / slabs
     const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4) ? params->waves_per_tile == 4

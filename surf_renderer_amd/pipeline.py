@@ -1,0 +1,133 @@
+"""Frames in flight: the single-process frame pipeline that bench.py times and tests/test_hip_pipeline.py checks.
+
+A frame is seven short kernels (clear, prep, count, scan, fill, render); the binning kernels are latency-bound, so
+`n_inflight` frames run on their own HIP streams with their own scratch and output slab, and the binning of one frame
+overlaps the render kernel of another.  Each (output slab, scratch) pair's kernel sequence can be captured once as a
+hipGraph and replayed (one host call per frame instead of seven launches).  Everything a replay touches is owned by
+this object and stays alive with it: the scene buffers, the scratch, the slabs and the graphs.
+
+Reference call it stands for: a loop of ``render(scene)`` calls over one resident scene
+(diffrend/torch/batch_render.py:36-53, torch/GAN/gan.py:325-378).
+"""
+from __future__ import annotations
+
+import sys
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib, renderer
+
+
+def slab_views(slab: torch.Tensor, width: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rows, 4W) fp32 slab -> image (rows, W, 3) and depth (rows, W) views: [W x rgb | W x depth] per row, so one
+    transfer moves both."""
+    rows = slab.shape[0]
+    off = slab.storage_offset()
+    return (slab.as_strided((rows, width, 3), (4 * width, 3, 1), off),
+            slab.as_strided((rows, width), (4 * width, 1), off + 3 * width))
+
+
+class FramePipeline:
+    """`n_inflight` frames of one resident scene in flight on their own streams.
+
+    submit(ev)   enqueue the next frame into slab (count % n_inflight): graph replay when graphs are on and no timing
+                 event pair is asked for, eager launches otherwise.  Never synchronises the host.
+    sync()       wait for everything submitted.
+    verify()     render every slab's rows once more, eagerly on the current stream, and compare bit for bit.
+    """
+
+    def __init__(self, buf: renderer.SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
+                 n_inflight: int = 3, mode: str = "auto", graphs: bool = True, strict_graphs: bool = False,
+                 slabs: Optional[List[torch.Tensor]] = None):
+        self.buf, self.cam, self.mode = buf, cam, mode
+        self.device = buf.device
+        self.width, self.height = renderer.frame_size(cam)
+        self.rows = (0, self.height) if rows is None else (int(rows[0]), int(rows[1]))
+        h = self.rows[1] - self.rows[0]
+        self.n = int(n_inflight)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+        self.scratch = [buf.new_workspace(self.width, self.height) for _ in range(self.n)]
+        self.slabs = slabs if slabs is not None else \
+            [torch.empty((h, 4 * self.width), dtype=torch.float32, device=self.device) for _ in range(self.n)]
+        if len(self.slabs) != self.n:
+            raise ValueError("one output slab per frame in flight")
+        self.graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.n
+        self.use_graphs = bool(graphs)
+        self.count = 0
+        self._since_poison: Optional[int] = None
+        if self.use_graphs:
+            self._capture(strict_graphs)
+
+    def _render(self, b: int, ev=None) -> None:
+        image, depth = slab_views(self.slabs[b], self.width)
+        renderer.render_buffers(self.buf, self.cam, rows=self.rows, mode=self.mode, out=(image, depth, None),
+                                events=ev, workspace=self.scratch[b])
+
+    def _capture(self, strict: bool) -> None:
+        """One hipGraph per (slab, scratch) pair, captured up front on that pair's stream."""
+        torch.cuda.synchronize(self.device)
+        try:
+            for b in range(self.n):
+                with torch.cuda.stream(self.streams[b]):
+                    self._render(b)                              # warm: module load, allocator
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                # thread_local: only this thread's calls belong to the capture (a caller may have helper threads)
+                with torch.cuda.graph(g, stream=self.streams[b], capture_error_mode="thread_local"):
+                    self._render(b)
+                self.graphs[b] = g
+        except Exception as exc:                                 # capture unsupported here: stay eager, say so
+            if strict:
+                raise
+            print(f"[pipeline] hipGraph capture failed ({exc!r}); eager launches", file=sys.stderr)
+            self.graphs = [None] * self.n
+            self.use_graphs = False
+        torch.cuda.synchronize(self.device)
+
+    @property
+    def captured(self) -> int:
+        return sum(g is not None for g in self.graphs)
+
+    def submit(self, ev=None) -> int:
+        b = self.count % self.n
+        self.count += 1
+        if self._since_poison is not None:
+            self._since_poison += 1
+        g = self.graphs[b] if ev is None else None
+        with torch.cuda.stream(self.streams[b]):
+            if g is not None:
+                g.replay()
+            else:
+                self._render(b, ev)
+        return b
+
+    def sync(self) -> None:
+        for s in self.streams:
+            s.synchronize()
+
+    def poison(self) -> None:
+        """Overwrite every output slab with NaN bit patterns (and wait): a later verify() then proves that the frames
+        submitted in between really wrote their slabs -- a replay that silently did nothing would leave the poison."""
+        self.sync()
+        for t in self.slabs:
+            t.view(torch.int32).fill_(-1)
+        torch.cuda.synchronize(self.device)
+        self._since_poison = 0
+
+    def verify(self) -> int:
+        """Every slab rendered into (since the last poison(), if any) equals a fresh eager render of the same rows,
+        bit for bit.  Returns the number of slabs compared; raises on the first mismatch."""
+        self.sync()
+        ref = torch.empty_like(self.slabs[0])
+        image, depth = slab_views(ref, self.width)
+        renderer.render_buffers(self.buf, self.cam, rows=self.rows, mode=self.mode, out=(image, depth, None))
+        torch.cuda.synchronize(self.device)
+        done = self.count if self._since_poison is None else self._since_poison
+        n = min(self.n, done)
+        for b in [(self.count - 1 - i) % self.n for i in range(n)]:
+            if not torch.equal(self.slabs[b].view(torch.int32), ref.view(torch.int32)):
+                bad = int((self.slabs[b].view(torch.int32) != ref.view(torch.int32)).sum())
+                raise RuntimeError(f"frame slab {b} ({'graph replay' if self.graphs[b] is not None else 'eager'} on "
+                                   f"stream {b}) differs from the eager render in {bad} words")
+        return n
