@@ -200,7 +200,14 @@ __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) { bin_fill_body(F)
 constexpr uint32_t kOrdMask = 0xFFFu;
 constexpr int32_t kNoKey = 0;
 constexpr float kNoEstimate = 1.0e30f;
-constexpr int kSerialSlowMax = 2;           // more undecided pixels than this in a round: lane-parallel re-sweep
+#ifndef SRH_SERIAL_SLOW_MAX
+#define SRH_SERIAL_SLOW_MAX 2
+#endif
+constexpr int kSerialSlowMax = SRH_SERIAL_SLOW_MAX;   // more undecided pixels than this in a round: lane-parallel re-sweep
+#ifndef SRH_KEYS
+#define SRH_KEYS 4
+#endif
+constexpr int kKeys = SRH_KEYS;             // keys tracked per pixel: kKeys - 1 are confirmed in fp64, the last is a bound only
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -400,7 +407,7 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
-    Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
+    if (kKeys == 4) Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
     Q.k3[j] = imed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = imed3(Q.k1[j], key, Q.k2[j]);
     Q.k1[j] = max(Q.k1[j], key);
@@ -749,13 +756,35 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
     const int r = min(r_raw, F.row1 - 1);
     QuadState Q;
     Q.rf = (float)r;
+    // |D|^2 of the quad's four pixels: D(c0 + j) = D(c0) + j Dc, so |D|^2 = A + j (B + j C) with A = |D(c0)|^2,
+    // B = 2 D(c0).Dc, C = |Dc|^2 -- one fp64 ray instead of four (equal to ~1e-16 relative; only the fp32 bound uses it)
+    double len2[4];
+#ifdef SRH_ABL_LEN2_EACH
+#pragma unroll
+    for (int j = 0; j < 4; ++j) len2[j] = pixel_len2(F, min(c0 + j, F.W - 1), r);
+#else
+    {
+      const double xs = c0 * F.step_x + -1.0, ys = (F.H > 1 && r == F.H - 1) ? -1.0 : (r * F.step_y + 1.0);
+      const double X = xs * F.half_w, Y = ys * F.half_h, sx = F.step_x * F.half_w;
+      double A = 0.0, B = 0.0, C = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double v = __builtin_fma(F.bx[i], X, __builtin_fma(F.by[i], Y, -F.bz[i] * F.focal)), dc = F.bx[i] * sx;
+        A = __builtin_fma(v, v, A);
+        B = __builtin_fma(v, dc, B);
+        C = __builtin_fma(dc, dc, C);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) len2[j] = __builtin_fma((double)j, __builtin_fma((double)j, C, 2.0 * B), A);
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = min(c0 + j, F.W - 1);
       Q.cf[j >> 1][j & 1] = (float)c;
       // 1 / |D| = rsq(|D|^2): the fp32 conversion (half an ulp of |D|^2) and v_rsq_f32 (1 ulp) together stay below
       // 1.3 * 2^-23 relative, well inside the 2^-20 the depth estimate reserves (plane_estimate_record)
-      Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rsqf((float)pixel_len2(F, c, r));
+      Q.rlen[j >> 1][j & 1] = __builtin_amdgcn_rsqf((float)len2[j]);
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps
@@ -778,7 +807,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         const int32_t keys[4] = {o.k1, o.k2, o.k3, o.k4};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          m4 = imed3(m3, keys[t], m4);
+          if (kKeys == 4) m4 = imed3(m3, keys[t], m4);
           m3 = imed3(m2, keys[t], m3);
           m2 = imed3(m1, keys[t], m2);
           m1 = max(m1, keys[t]);
@@ -873,12 +902,13 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         // first one always; the next ones after a near miss at an ellipse edge or for nearly coplanar primitives).
         // A saturated ordinal does not identify its primitive: such a pixel confirms everything on the slow path.
         const int32_t keys[3] = {p.k1, p.k2, p.k3};
+        const int32_t sentinel = kKeys == 4 ? p.k4 : p.k3;
         bool saturated = false;
         // a key still "reaches" the confirmed depth iff its inverse-depth bound is >= reach_of(bound)
         // (one reciprocal per confirmation instead of one per key; 0 while nothing is confirmed)
         float reach = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < kKeys - 1; ++q) {
           const int32_t key = keys[q];
           if (key != kNoKey && !saturated && key_inv(key) >= reach) {
             if (key_saturated(key)) {
@@ -895,7 +925,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
           }
         }
         // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
-        slow = saturated || (p.k4 != kNoKey && key_inv(p.k4) >= reach);
+        slow = saturated || (sentinel != kNoKey && key_inv(sentinel) >= reach);
         if (slow) { g1 = g2 = -1; }           // the slow path re-confirms; cheaper than excluding three indices
       }
 #endif

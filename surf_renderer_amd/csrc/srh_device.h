@@ -292,16 +292,17 @@ __device__ __forceinline__ double spec_pow_f32(double base, double expo) {
 
 // image ** gamma of the tonemap (numpy/renderer.py:140-142) evaluated in fp32: x is already within half an
 // fp32 ulp of the reference value.  x^g = exp2(g * log2 x) on the hardware v_log_f32 / v_exp_f32 (1 ulp each):
-// the error of y = g log2 x is at most 2^-23 |y|, so with |y| <= 12 the result is off by at most
-// ln2 * 12 * 2^-23 + 2^-23 = 1.1e-6 relative (parity budget 2e-6).  Everything else -- zero, inf, nan, subnormal or
-// huge arguments, |y| > 12 -- takes the library powf (~2 ulp), so all special values are the reference's; only the
-// frequent 0^g (background, back-facing fragments) with g > 0 stays on the direct path.
+// the error of y = g log2 x is at most 2^-23 |y|, so for |y| <= 12 the result is off by at most
+// ln2 * 12 * 2^-23 + 2^-23 = 1.1e-6 relative (parity budget 2e-6 relative + 2e-7 absolute).
 __device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
   if (!F.tonemap) return (float)v;
   const float x = (float)v, g = (float)F.gamma;
   const float y = g * __builtin_amdgcn_logf(x);
-  const bool direct = (x >= 1e-30f && x <= 1e30f && fabsf(y) <= 12.0f) || (x == 0.0f && g > 0.0f);   // 0^g = exp2(-inf) = 0
-  if (direct) return __builtin_amdgcn_exp2f(y);
+  // direct path iff gamma > 0 and y <= 12.  Below y = -12 the relative error of exp2(y) grows (ln2 |y| 2^-23) but the
+  // result is < 2.5e-4, so the ABSOLUTE error stays under 3e-9 (budget 2e-7); x = 0 and denormal x give -inf -> 0, off
+  // by at most 1e-30 absolute.  NaN, +inf and y > 12 fail the compare and take the library powf (~2 ulp, all the
+  // reference's special values); gamma <= 0 (never in practice) always does.
+  if (g > 0.0f && y <= 12.0f) return __builtin_amdgcn_exp2f(y);
   return powf(x, g);
 }
 
@@ -339,7 +340,10 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
   const SegDev& S = F.seg[s];
   const int li = win - S.first;
   const double* org = origin ? origin : F.o;     // orthographic rays start on the image plane, not at the eye
-  const double p[3] = {org[0] + z * d[0], org[1] + z * d[1], org[2] + z * d[2]};
+  // From here on the arithmetic feeds only the fp32 image (2e-7 + 2e-6 |x| against the reference): multiply-adds are
+  // written as explicit FMAs -- every kernel that inlines this function then rounds identically, so the render modes
+  // stay bit-identical to one another -- and the reciprocal square roots are Newton-refined hardware seeds.
+  const double p[3] = {__builtin_fma(z, d[0], org[0]), __builtin_fma(z, d[1], org[1]), __builtin_fma(z, d[2], org[2])};
 
   double n[3];
   if (S.type == SRH_PRIM_SPHERE) {
@@ -411,12 +415,13 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     for (int l = 0; l < F.nlights; ++l) {
       const double* L = F.lights64 + 6 * l;
       const double v[3] = {L[0] - p[0], L[1] - p[1], L[2] - p[2]};
-      const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-      // |l| <= 0 -> 1 (Q7): the light sits exactly on the fragment and contributes n . 0 = 0
-      const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;
-      const double ndotl = ((n[0] * v[0] + n[1] * v[1]) + n[2] * v[2]) * inv;
+      const double len2 = __builtin_fma(v[2], v[2], __builtin_fma(v[1], v[1], v[0] * v[0]));
+      // |l| <= 0 -> 1 (Q7): the light sits exactly on the fragment and contributes n . 0 = 0.  Clamping |l|^2 at the
+      // smallest normal double gives the same 0 (0 x finite) without a compare and two selects; a NaN still ends NaN.
+      const double inv = rsqrt_newton(fmax(len2, 2.2250738585072014e-308));
+      const double ndotl = __builtin_fma(n[2], v[2], __builtin_fma(n[1], v[1], n[0] * v[0])) * inv;
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) im[ch] += ndotl * L[3 + ch];
+      for (int ch = 0; ch < 3; ++ch) im[ch] = __builtin_fma(ndotl, L[3 + ch], im[ch]);
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) im[ch] *= alb[ch];

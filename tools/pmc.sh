@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C="$1"; shift
 rm -rf gpurun_out/pmc_tmp
-timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_tmp -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > gpurun_out/pmc_tmp.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_tmp -- python3 bench.py --no-cpu-baseline --no-check --warmup-ms 0 --steps 3 --warmup 1 "$@" > gpurun_out/pmc_tmp.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_tmp/*/*counter_collection.csv")[0]
