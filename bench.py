@@ -68,6 +68,9 @@ def parse():
                     help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
                          "overlap the render kernel of another.  Default 3 (measured: 1 -> 5.3k, 2 -> 7.7k, 3 -> 8.1k, "
                          "4 -> 7.1k frames/s on one MI355X)")
+    ap.add_argument("--schedule", default="frames", choices=["frames", "stages"],
+                    help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
+                         "one stream for every frame's binning kernels, one for every frame's render kernel")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
                          "(default), or one gather per frame to rank 0")
@@ -436,7 +439,7 @@ def main():
         # single process: surf_renderer_amd.pipeline.FramePipeline (the same object tests/test_hip_pipeline.py checks)
         from surf_renderer_amd.pipeline import FramePipeline
         pipe = FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
-                             strict_graphs=args.graph == "on")
+                             strict_graphs=args.graph == "on", schedule=args.schedule)
         graph_state["on"] = pipe.use_graphs
         graph_state["captured"] = pipe.captured
         n_buf, slabs = n_str, pipe.slabs
@@ -611,7 +614,7 @@ def main():
             "config": {"workload": "BASELINE configs[4]: 100k synthetic disk splats, 2048x2048, forward render, "
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
-                       "frames_in_flight": n_str,
+                       "frames_in_flight": n_str, "schedule": args.schedule if pipe is not None else "frames",
                        "launch": f"hipGraph replay ({graph_state['captured']} graphs)"
                                  if graph_state["on"] and graph_state["captured"] else "eager",
                        "warmup_steps_run": warm_steps, "warmup_ms_run": warm_ms,

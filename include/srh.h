@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 7
+#define SRH_ABI_VERSION 8
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -139,7 +139,15 @@ typedef struct SrhParams {
                                    srh_shadow_shade wrote for this frame, or NULL (no shadows) */
   const int32_t* view_row0;     /* srh_render_views only: HOST array of n_views first rows; view v renders rows
                                    [view_row0[v], view_row0[v] + row1 - row0).  NULL = every view renders [row0, row1) */
+  int32_t stages;               /* srh_render_fwd, binned mode: 0 = the whole frame; SRH_STAGE_BIN = only the per-frame
+                                   records and tile bins (into the workspace); SRH_STAGE_RENDER = only the render kernel,
+                                   from the bins a SRH_STAGE_BIN call with the same arguments left in the workspace.
+                                   Lets a caller run the latency-bound binning of frame i+1 on one stream beside the
+                                   render kernel of frame i on another (surf_renderer_amd/pipeline.py) */
+  int32_t reserved0;
 } SrhParams;
+
+enum { SRH_STAGE_BIN = 1, SRH_STAGE_RENDER = 2 };
 
 int srh_abi_version(void);
 const char* srh_last_error(void);

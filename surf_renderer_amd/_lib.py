@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -55,7 +55,9 @@ class SrhParams(C.Structure):
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("visibility", C.c_void_p),
-                ("view_row0", C.c_void_p)]
+                ("view_row0", C.c_void_p), ("stages", C.c_int32), ("reserved0", C.c_int32)]
+
+STAGE_BIN, STAGE_RENDER = 1, 2
 
 
 class SrhGrads(C.Structure):

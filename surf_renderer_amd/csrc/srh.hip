@@ -735,18 +735,14 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   // orthographic frames take the all-pairs fp64 kernel of their own, whatever mode is asked for
   const int mode = F.ortho ? SRH_MODE_EXACT : (params->mode == SRH_MODE_AUTO ? SRH_MODE_BINNED : params->mode);
   hipStream_t st = (hipStream_t)stream;
-#ifdef SRH_ABL_RENDERONLY   // diagnostic build: after the first 16 calls only the render kernel runs (bins are reused)
-  static int abl_calls = 0;
-  const bool abl_skip_binning = ++abl_calls > 16;
-#else
-  const bool abl_skip_binning = false;
-#endif
-#ifdef SRH_ABL_BINONLY      // diagnostic build: after the first 16 calls the render kernel is skipped
-  static int abl_calls2 = 0;
-  const bool abl_skip_render = ++abl_calls2 > 16;
-#else
-  const bool abl_skip_render = false;
-#endif
+  // SrhParams.stages splits the frame for callers that pipeline it over two streams: SRH_STAGE_BIN = per-frame records
+  // and tile bins into the workspace, SRH_STAGE_RENDER = the render kernel from bins a previous SRH_STAGE_BIN call with
+  // the same arguments left there.  0 = both.
+  const int stages = params->stages == 0 ? (SRH_STAGE_BIN | SRH_STAGE_RENDER) : params->stages;
+  if (stages & ~(SRH_STAGE_BIN | SRH_STAGE_RENDER)) return fail(SRH_E_TYPE, "unknown stages mask %d", params->stages);
+  if (stages != (SRH_STAGE_BIN | SRH_STAGE_RENDER) && mode != SRH_MODE_BINNED)
+    return fail(SRH_E_TYPE, "SrhParams.stages splits binned frames only");
+  const bool abl_skip_binning = !(stages & SRH_STAGE_BIN), abl_skip_render = !(stages & SRH_STAGE_RENDER);
   if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
     hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);

@@ -39,14 +39,27 @@ class FramePipeline:
 
     def __init__(self, buf: renderer.SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                  n_inflight: int = 3, mode: str = "auto", graphs: bool = True, strict_graphs: bool = False,
-                 slabs: Optional[List[torch.Tensor]] = None):
+                 slabs: Optional[List[torch.Tensor]] = None, schedule: str = "frames"):
+        """``schedule='frames'``: frame k runs whole on stream k % n_inflight.  ``schedule='stages'``: two streams, one
+        for every frame's binning kernels and one for every frame's render kernel (``SrhParams.stages``): the
+        latency-bound binning of frame k+1 runs beside the render kernel of frame k, render kernels never share the
+        GPU with one another, and a frame's (slab, scratch) pair k % n_inflight is reused only after its render."""
+        if schedule not in ("frames", "stages"):
+            raise ValueError("schedule must be 'frames' or 'stages'")
+        if schedule == "stages" and mode not in ("auto", "binned"):
+            raise ValueError("schedule='stages' needs the binned mode")
+        self.schedule = schedule
         self.buf, self.cam, self.mode = buf, cam, mode
         self.device = buf.device
         self.width, self.height = renderer.frame_size(cam)
         self.rows = (0, self.height) if rows is None else (int(rows[0]), int(rows[1]))
         h = self.rows[1] - self.rows[0]
         self.n = int(n_inflight)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+        n_streams = 2 if schedule == "stages" else self.n
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_streams)]
+        self._bin_done = [torch.cuda.Event() for _ in range(self.n)] if schedule == "stages" else []
+        self._render_done: List[Optional[torch.cuda.Event]] = [None] * self.n
+        self.bin_graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.n
         self.scratch = [buf.new_workspace(self.width, self.height) for _ in range(self.n)]
         self.slabs = slabs if slabs is not None else \
             [torch.empty((h, 4 * self.width), dtype=torch.float32, device=self.device) for _ in range(self.n)]
@@ -59,29 +72,38 @@ class FramePipeline:
         if self.use_graphs:
             self._capture(strict_graphs)
 
-    def _render(self, b: int, ev=None) -> None:
+    def _render(self, b: int, ev=None, stages: int = 0) -> None:
         image, depth = slab_views(self.slabs[b], self.width)
         renderer.render_buffers(self.buf, self.cam, rows=self.rows, mode=self.mode, out=(image, depth, None),
-                                events=ev, workspace=self.scratch[b])
+                                events=ev, workspace=self.scratch[b], stages=stages)
 
     def _capture(self, strict: bool) -> None:
         """One hipGraph per (slab, scratch) pair, captured up front on that pair's stream."""
         torch.cuda.synchronize(self.device)
+
+        def capture(stream, b, stages):
+            g = torch.cuda.CUDAGraph()
+            # thread_local: only this thread's calls belong to the capture (a caller may have helper threads)
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                self._render(b, stages=stages)
+            return g
+
         try:
             for b in range(self.n):
-                with torch.cuda.stream(self.streams[b]):
+                with torch.cuda.stream(self.streams[0 if self.schedule == "stages" else b]):
                     self._render(b)                              # warm: module load, allocator
                 torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                # thread_local: only this thread's calls belong to the capture (a caller may have helper threads)
-                with torch.cuda.graph(g, stream=self.streams[b], capture_error_mode="thread_local"):
-                    self._render(b)
-                self.graphs[b] = g
+                if self.schedule == "stages":
+                    self.bin_graphs[b] = capture(self.streams[0], b, _lib.STAGE_BIN)
+                    self.graphs[b] = capture(self.streams[1], b, _lib.STAGE_RENDER)
+                else:
+                    self.graphs[b] = capture(self.streams[b], b, 0)
         except Exception as exc:                                 # capture unsupported here: stay eager, say so
             if strict:
                 raise
             print(f"[pipeline] hipGraph capture failed ({exc!r}); eager launches", file=sys.stderr)
             self.graphs = [None] * self.n
+            self.bin_graphs = [None] * self.n
             self.use_graphs = False
         torch.cuda.synchronize(self.device)
 
@@ -94,6 +116,26 @@ class FramePipeline:
         self.count += 1
         if self._since_poison is not None:
             self._since_poison += 1
+        if self.schedule == "stages":
+            sb, sr = self.streams
+            with torch.cuda.stream(sb):
+                if self._render_done[b] is not None:
+                    sb.wait_event(self._render_done[b])          # this pair's previous frame has been rendered
+                if self.bin_graphs[b] is not None:
+                    self.bin_graphs[b].replay()
+                else:
+                    self._render(b, stages=_lib.STAGE_BIN)
+                self._bin_done[b].record(sb)
+            with torch.cuda.stream(sr):
+                sr.wait_event(self._bin_done[b])
+                if self.graphs[b] is not None and ev is None:
+                    self.graphs[b].replay()
+                else:
+                    self._render(b, ev, stages=_lib.STAGE_RENDER)
+                if self._render_done[b] is None:
+                    self._render_done[b] = torch.cuda.Event()
+                self._render_done[b].record(sr)
+            return b
         g = self.graphs[b] if ev is None else None
         with torch.cuda.stream(self.streams[b]):
             if g is not None:

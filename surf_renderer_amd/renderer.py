@@ -334,11 +334,13 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                    want_nearest: bool = True, events: Optional[_lib.EventPair] = None,
                    workspace: Optional[torch.Tensor] = None, shading: str = "numpy", double_sided: bool = False,
                    use_quartic: bool = False, aux: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = None,
-                   waves_per_tile: int = 0):
+                   waves_per_tile: int = 0, stages: int = 0):
     """One frame (or the row slab ``rows=(r0, r1)`` of it) from resident buffers.  Everything is
     enqueued on the current stream of ``buf.device``; nothing synchronises.  ``out`` may supply
     preallocated (image (h,W,3) f32, depth (h,W) f32, nearest (h,W) i32 or None).  ``workspace`` overrides the
     buffers' own scratch: frames in flight on different streams each need their own (``new_workspace``).
+    ``stages`` (``_lib.STAGE_BIN`` / ``_lib.STAGE_RENDER``, 0 = both) splits a binned frame into its binning kernels and its
+    render kernel, for a caller that runs them on two streams (``pipeline.FramePipeline``).
     ``shading='torch'`` selects the torch backend's semantics (Phong with attenuation / specular / ambient,
     ``double_sided``, ``use_quartic``, orthonormal camera, far+1 background); ``aux=(normal, pos)`` are optional
     dense (h,W,3) f32 outputs."""
@@ -370,7 +372,8 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                             image_row_stride=image.stride(0) if h > 1 else 0,
                             depth_row_stride=depth.stride(0) if h > 1 else 0,
                             nearest_row_stride=nearest.stride(0) if (nearest is not None and h > 1) else 0,
-                            ev_start=events.start if events else None, ev_stop=events.stop if events else None)
+                            ev_start=events.start if events else None, ev_stop=events.stop if events else None,
+                            stages=int(stages))
     if workspace is None:
         workspace = buf.ensure_workspace(width, height)
     with torch.cuda.device(buf.device):
