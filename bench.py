@@ -68,9 +68,11 @@ def parse():
                     help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
                          "overlap the render kernel of another.  Default 3 (measured: 1 -> 5.3k, 2 -> 7.7k, 3 -> 8.1k, "
                          "4 -> 7.1k frames/s on one MI355X)")
-    ap.add_argument("--schedule", default="frames", choices=["frames", "stages"],
+    ap.add_argument("--schedule", default="frames", choices=["frames", "stages", "render-only", "bin-only"],
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
                          "one stream for every frame's binning kernels, one for every frame's render kernel")
+    ap.add_argument("--render-streams", type=int, default=2, help="--schedule stages: streams the render kernels alternate over")
+    ap.add_argument("--flat-priority", action="store_true", help="--schedule stages: do not raise the render streams' priority")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
                          "(default), or one gather per frame to rank 0")
@@ -439,7 +441,8 @@ def main():
         # single process: surf_renderer_amd.pipeline.FramePipeline (the same object tests/test_hip_pipeline.py checks)
         from surf_renderer_amd.pipeline import FramePipeline
         pipe = FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
-                             strict_graphs=args.graph == "on", schedule=args.schedule)
+                             strict_graphs=args.graph == "on", schedule=args.schedule,
+                             render_streams=args.render_streams, prioritise_render=not args.flat_priority)
         graph_state["on"] = pipe.use_graphs
         graph_state["captured"] = pipe.captured
         n_buf, slabs = n_str, pipe.slabs

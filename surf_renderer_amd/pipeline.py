@@ -39,14 +39,17 @@ class FramePipeline:
 
     def __init__(self, buf: renderer.SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                  n_inflight: int = 3, mode: str = "auto", graphs: bool = True, strict_graphs: bool = False,
-                 slabs: Optional[List[torch.Tensor]] = None, schedule: str = "frames"):
+                 slabs: Optional[List[torch.Tensor]] = None, schedule: str = "frames", render_streams: int = 2,
+                 prioritise_render: bool = True):
         """``schedule='frames'``: frame k runs whole on stream k % n_inflight.  ``schedule='stages'``: two streams, one
         for every frame's binning kernels and one for every frame's render kernel (``SrhParams.stages``): the
         latency-bound binning of frame k+1 runs beside the render kernel of frame k, render kernels never share the
         GPU with one another, and a frame's (slab, scratch) pair k % n_inflight is reused only after its render."""
-        if schedule not in ("frames", "stages"):
+        # 'render-only' / 'bin-only': diagnostics -- every stream replays just that half of its frame (the bins of the
+        # warm-up frame stay valid: same scene, same camera), to price each half of the pipeline on its own
+        if schedule not in ("frames", "stages", "render-only", "bin-only"):
             raise ValueError("schedule must be 'frames' or 'stages'")
-        if schedule == "stages" and mode not in ("auto", "binned"):
+        if schedule != "frames" and mode not in ("auto", "binned"):
             raise ValueError("schedule='stages' needs the binned mode")
         self.schedule = schedule
         self.buf, self.cam, self.mode = buf, cam, mode
@@ -55,8 +58,15 @@ class FramePipeline:
         self.rows = (0, self.height) if rows is None else (int(rows[0]), int(rows[1]))
         h = self.rows[1] - self.rows[0]
         self.n = int(n_inflight)
-        n_streams = 2 if schedule == "stages" else self.n
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_streams)]
+        if schedule == "stages":
+            # streams[0]: every frame's binning kernels; streams[1:]: the render kernels, frame k on 1 + k % R.  The
+            # render streams get the higher priority: binning waves then only take what the render kernels leave.
+            self.n_render = max(1, int(render_streams))
+            self.streams = [torch.cuda.Stream(self.device, priority=0)] + \
+                [torch.cuda.Stream(self.device, priority=-1 if prioritise_render else 0) for _ in range(self.n_render)]
+        else:
+            self.n_render = 0
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
         self._bin_done = [torch.cuda.Event() for _ in range(self.n)] if schedule == "stages" else []
         self._render_done: List[Optional[torch.cuda.Event]] = [None] * self.n
         self.bin_graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.n
@@ -95,9 +105,9 @@ class FramePipeline:
                 torch.cuda.synchronize(self.device)
                 if self.schedule == "stages":
                     self.bin_graphs[b] = capture(self.streams[0], b, _lib.STAGE_BIN)
-                    self.graphs[b] = capture(self.streams[1], b, _lib.STAGE_RENDER)
+                    self.graphs[b] = capture(self.streams[1 + b % self.n_render], b, _lib.STAGE_RENDER)
                 else:
-                    self.graphs[b] = capture(self.streams[b], b, 0)
+                    self.graphs[b] = capture(self.streams[b], b, self._half())
         except Exception as exc:                                 # capture unsupported here: stay eager, say so
             if strict:
                 raise
@@ -117,7 +127,7 @@ class FramePipeline:
         if self._since_poison is not None:
             self._since_poison += 1
         if self.schedule == "stages":
-            sb, sr = self.streams
+            sb, sr = self.streams[0], self.streams[1 + (self.count - 1) % self.n_render]
             with torch.cuda.stream(sb):
                 if self._render_done[b] is not None:
                     sb.wait_event(self._render_done[b])          # this pair's previous frame has been rendered
@@ -141,8 +151,11 @@ class FramePipeline:
             if g is not None:
                 g.replay()
             else:
-                self._render(b, ev)
+                self._render(b, ev, stages=self._half())
         return b
+
+    def _half(self) -> int:
+        return {"render-only": _lib.STAGE_RENDER, "bin-only": _lib.STAGE_BIN}.get(self.schedule, 0)
 
     def sync(self) -> None:
         for s in self.streams:
