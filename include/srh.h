@@ -10,10 +10,15 @@
  *
  * Conventions
  *   - Every device buffer is allocated and freed by the caller.  The library keeps no device memory
- *     and no global state between calls; all work is enqueued on the stream that is passed in and no
- *     entry point synchronises.  (One exception, srh_render_views: its per-view frame descriptors go
- *     through a pinned staging buffer and a ring of four batches in constant memory that the library
- *     owns; a call waits only if the slot it reuses is still in flight, four calls back.)
+ *     and no state between calls; all work is enqueued on the stream that is passed in and no entry
+ *     point synchronises.  One documented exception, srh_render_views: its per-view frame descriptors
+ *     go through pinned staging buffers and a ring of four batches in constant memory that the library
+ *     owns PER DEVICE (created on first use of a device, kept until the process ends, one mutex per
+ *     device; calls on different devices do not share anything).  A call waits on the host only if the
+ *     slot it reuses is still in flight, four calls back; it must be made with the stream's device
+ *     current, and it cannot be stream-captured (srh_render_fwd can).
+ *   - Thread safety: every entry point may be called from any thread; srh_last_error() is per thread.
+ *     Concurrent srh_render_views calls on one device serialise on that device's mutex.
  *   - Arrays use the reference's layouts (docs/scene_description.md, numpy/renderer.py:299-358):
  *     homogeneous 4-vectors, points w = 1, directions / normals w = 0, row-major, float32 on the
  *     device; index arrays are int32.
@@ -211,7 +216,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
  * and nearests (may be NULL).  Every kernel of the
  * frame pipeline is launched once for the whole batch (the view is a grid dimension), so small views cost neither
  * six launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
- * srh_workspace_bytes_views(...) bytes.  Calls are serialised on one pinned staging buffer per process. */
+ * srh_workspace_bytes_views(...) bytes.  Calls on one device are serialised on that device's staging ring. */
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views);
 int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,

@@ -792,13 +792,26 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
 // ---- many views of one scene per call ---------------------------------------------------------------------------
 namespace {
 size_t views_header_bytes(int n_views) { return align_up((size_t)n_views * sizeof(FrameDev)); }
-// Frame descriptors of the batches in flight: a ring of kViewRing slots, each a pinned host staging area, a range of
-// the device's constant-memory array g_view_frames (read by the render kernel) and an event that says "the batch
-// that used this slot has finished".  The other kernels read the copy at the head of the caller's workspace.
-FrameDev* g_stage[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
-hipEvent_t g_slot_done[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
-unsigned g_next_slot = 0;
-std::mutex g_stage_mu;                // one call at a time claims a slot and submits
+// Frame descriptors of the batches in flight, PER DEVICE: a ring of kViewRing slots, each a pinned host staging area, a
+// range of that device's constant-memory array g_view_frames (read by the render kernel) and an event that says "the
+// batch that used this slot has finished".  The other kernels read the copy at the head of the caller's workspace.
+// This is the one piece of state the library owns (include/srh.h, Conventions); it is created on first use of a
+// device, lives until the process ends, and one mutex per device serialises claim + submit.
+constexpr int kMaxDevices = 64;
+struct ViewRing {
+  std::mutex mu;
+  FrameDev* stage[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t done[kViewRing] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned next = 0;
+};
+ViewRing g_rings[kMaxDevices];
+
+// the device a call works on: the stream's own device when HIP can tell, else the calling thread's current device
+int device_of(hipStream_t st, int* dev) {
+  if (st && hipStreamGetDevice(st, dev) == hipSuccess) return SRH_OK;
+  const hipError_t e = hipGetDevice(dev);
+  return e == hipSuccess ? SRH_OK : hip_fail(e, "hipGetDevice");
+}
 }  // namespace
 
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views) {
@@ -830,18 +843,35 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     return fail(SRH_E_RANGE, "workspace holds %zu bytes, %d views need %zu", workspace_bytes, n_views,
                 head + (size_t)n_views * one);
   hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lock(g_stage_mu);
+  int dev = 0;
+  if (int rc = device_of(st, &dev)) return rc;
+  if (dev < 0 || dev >= kMaxDevices) return fail(SRH_E_RANGE, "device %d: srh_render_views supports devices 0..%d", dev, kMaxDevices - 1);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != dev)
+    return fail(SRH_E_RANGE, "srh_render_views: the stream belongs to device %d but device %d is current", dev, cur);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(SRH_E_TYPE, "srh_render_views cannot be stream-captured (it waits on an event and stages through "
+                            "library-owned pinned memory); capture srh_render_fwd calls instead");
+  ViewRing& ring = g_rings[dev];
+  std::lock_guard<std::mutex> lock(ring.mu);
   // claim the next ring slot; its previous batch must have finished (host wait only when kViewRing batches are behind)
-  const unsigned slot = g_next_slot++ % kViewRing;
-  if (!g_slot_done[slot]) {
-    const hipError_t ee = hipEventCreateWithFlags(&g_slot_done[slot], hipEventDisableTiming);
-    if (ee != hipSuccess) { g_slot_done[slot] = nullptr; return hip_fail(ee, "hipEventCreate"); }
-    const hipError_t em = hipHostMalloc((void**)&g_stage[slot], (size_t)kMaxViewsPerCall * sizeof(FrameDev), hipHostMallocDefault);
-    if (em != hipSuccess) { g_stage[slot] = nullptr; return hip_fail(em, "hipHostMalloc(frames)"); }
+  const unsigned slot = ring.next % kViewRing;
+  if (!ring.stage[slot]) {
+    // staging first, then the event: a slot is usable only when it has both
+    FrameDev* mem = nullptr;
+    const hipError_t em = hipHostMalloc((void**)&mem, (size_t)kMaxViewsPerCall * sizeof(FrameDev), hipHostMallocDefault);
+    if (em != hipSuccess) return hip_fail(em, "hipHostMalloc(frames)");
+    hipEvent_t ev = nullptr;
+    const hipError_t ee = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (ee != hipSuccess) { (void)hipHostFree(mem); return hip_fail(ee, "hipEventCreate"); }
+    ring.stage[slot] = mem;
+    ring.done[slot] = ev;
   } else {
-    (void)hipEventSynchronize(g_slot_done[slot]);
+    const hipError_t es = hipEventSynchronize(ring.done[slot]);
+    if (es != hipSuccess) return hip_fail(es, "hipEventSynchronize(slot)");
   }
-  FrameDev* stage = g_stage[slot];
+  FrameDev* stage = ring.stage[slot];
   char* ws = (char*)workspace;
   WsLayout L;
   for (int v = 0; v < n_views; ++v) {
@@ -885,7 +915,14 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
     else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups, V), dim3(256), 0, st, base, images, depths, nearests);
   }
-  (void)hipEventRecord(g_slot_done[slot], st);
+  // the slot is consumed only now: a call that failed validation above leaves the ring as it was
+  const hipError_t er = hipEventRecord(ring.done[slot], st);
+  ring.next++;
+  if (er != hipSuccess) {
+    // without the event nothing says when the staging may be reused: wait here, once, rather than race later
+    (void)hipStreamSynchronize(st);
+    return hip_fail(er, "hipEventRecord(slot)");
+  }
   e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "views launch");
 }

@@ -566,3 +566,76 @@ def test_render_views_refuses_what_it_cannot_do():
     with pytest.raises(Exception, match="perspective cameras only"):
         render_views(scene, [dict(scene["camera"], proj_type="ortho")], device="cuda:0", shading="torch")
     assert render_views(scene, cams, device="cuda:0", shadow=False)["image"].shape == (1, 24, 32, 3)
+
+
+def test_render_views_from_two_threads_on_one_device():
+    """srh_render_views keeps a per-device staging ring behind a mutex: two threads rendering different batches on
+    their own streams at the same time each get exactly what per-view render() gives (more calls than ring slots,
+    so slots are reused while the other thread is submitting)."""
+    import threading
+    from surf_renderer_amd import render, render_views, synthetic
+    scene = synthetic.bunny_splat_scene(64, 48)
+    rng = np.random.RandomState(11)
+
+    def cams(n):
+        out = []
+        for _ in range(n):
+            cam = dict(scene["camera"])
+            eye = rng.normal(size=3)
+            eye = 10.0 * eye / np.linalg.norm(eye)
+            cam["eye"] = [float(eye[0]), float(eye[1]), float(eye[2]), 1.0]
+            out.append(cam)
+        return out
+
+    jobs = [cams(11), cams(9)]
+    want = [[render({**scene, "camera": c}, device="cuda:0") for c in job] for job in jobs]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream("cuda:0")):
+                res = None
+                for _ in range(6):                      # 6 x ceil(n / 2) library calls per thread, 4 ring slots
+                    res = render_views(scene, jobs[i], device="cuda:0", batch=2)
+                torch.cuda.current_stream().synchronize()
+                got[i] = res
+        except Exception as exc:                        # noqa: BLE001 -- reported below, in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for v, single in enumerate(want[i]):
+            for k in ("image", "depth", "nearest"):
+                np.testing.assert_array_equal(got[i][k][v].cpu().numpy(), single[k].cpu().numpy(),
+                                              err_msg=f"thread {i} view {v} {k}")
+
+
+def test_render_views_refuses_stream_capture():
+    from surf_renderer_amd import _lib, renderer, synthetic
+    scene = synthetic.bunny_splat_scene(32, 32)
+    buf = renderer.flatten_scene(scene, "cuda:0")
+    cam = renderer.camera_struct(scene["camera"])
+    img = torch.empty((2, 32, 32, 3), device="cuda:0")
+    dep = torch.empty((2, 32, 32), device="cuda:0")
+    ws = renderer.render_views_buffers(buf, [cam, cam], img, dep)       # sizes the workspace, warms the ring
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(torch.cuda.Stream("cuda:0")):
+        g.capture_begin(capture_error_mode="thread_local")
+        try:
+            with pytest.raises(_lib.SrhError, match="stream-captured"):
+                renderer.render_views_buffers(buf, [cam, cam], img, dep, workspace=ws)
+            renderer.render_buffers(buf, cam, out=(img[0], dep[0], None))      # srh_render_fwd may be captured
+        finally:
+            g.capture_end()
+    g.replay()
+    torch.cuda.synchronize()
+    want, wdep, _ = renderer.render_buffers(buf, cam)
+    torch.cuda.synchronize()
+    assert torch.equal(img[0], want) and torch.equal(dep[0], wdep)
