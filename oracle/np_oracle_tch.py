@@ -347,3 +347,15 @@ def render(scene, double_sided=False, use_quartic=False, tile=2048, shadow=False
             image = image ** float(np.ravel(scene['tonemap']['gamma'])[0])
     return {'image': image.reshape(H, W, 3), 'depth': depth.reshape(H, W), 'nearest': nearest.reshape(H, W),
             'normal': normal_out.reshape(H, W, 3), 'pos': pos_out.reshape(H, W, 3)}
+
+
+def norm_depth_image(depth, far):
+    """`norm_depth_image_only` (diffrend/torch/renderer.py:245-249): background (depth >= far, i.e. the far + 1 fill)
+    takes the minimum depth, then (d - min) / (max - min).  Restated from the source text: the reference's own call
+    raises TypeError before reaching these lines (oracle/check_ref_kwargs.py), so this function is NOT pinned by a
+    reference output."""
+    depth = np.asarray(depth, dtype=np.float64)
+    lo = depth.min()
+    img = np.where(depth >= far, lo, depth)
+    with np.errstate(all="ignore"):
+        return (img - lo) / (depth.max() - lo)

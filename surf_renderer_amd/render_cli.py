@@ -56,6 +56,8 @@ def main(argv=None) -> int:
     ap.add_argument("--double_sided", action="store_true", help="hip, torch shading: flip normals towards the viewer")
     ap.add_argument("--shadow", action="store_true", help="hip, torch shading: shadow rays (all pairs)")
     args = ap.parse_args(argv)
+    if (args.shadow or args.double_sided) and not (args.use == "hip" and args.shading == "torch"):
+        ap.error("--shadow / --double_sided exist only in the torch backend's semantics: add --use hip --shading torch")
 
     from .scene import load_scene, scene_to_numpy
     vp = (args.width, args.height) if args.width and args.height else None

@@ -26,8 +26,14 @@ import torch
 from . import _lib
 from .scene import PRIM_CODE, _OBJ_FIELDS, unit_up
 
-# keyword arguments of the torch backend's render() that callers pass routinely (torch/renderer.py:
-# 152-168, 233-245, 291, 326-327); the hip backend accepts them so call sites need no edits.
+# keyword arguments of the torch backend's render() that callers pass routinely (torch/renderer.py:152-168, 233-245,
+# 291, 326-327); the hip backend accepts them so call sites need no edits.  What each does here:
+#   tiled, tile_size        memory knobs of the reference's (pixels x primitives) arrays: no effect on any output
+#   backface_culling        the reference only LABELS primitives (torch/utils.py:515-536) and never reads the labels:
+#                           every output is unchanged (oracle/check_ref_kwargs.py ran the reference both ways)
+#   vis_stat                True raises in the reference ('Removed Support for vis_stat', :235) and here
+#   norm_depth_image_only   `image` becomes the normalised depth of :245-249 (see render())
+#   shadow                  shadow rays (:291-314)
 _TORCH_ONLY_KWARGS = {"tiled", "tile_size", "backface_culling", "norm_depth_image_only", "vis_stat", "shadow"}
 
 
@@ -626,6 +632,16 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     return out
 
 
+def _norm_depth_image(depth: torch.Tensor, far: float) -> torch.Tensor:
+    """`norm_depth_image_only` of the torch backend (torch/renderer.py:245-249), on the far + 1 background depth:
+    background pixels take the minimum depth, then (d - min) / (max - min) -- the same tensor expression, so it is
+    differentiable through `depth` like the reference's.  The reference's own path raises before it gets here
+    (oracle/check_ref_kwargs.py), so this output is restated from the source, not pinned by a reference fixture."""
+    min_depth = depth.min()
+    image = torch.where(depth >= far, min_depth, depth)
+    return (image - min_depth) / (depth.max() - min_depth)
+
+
 class RenderResult(dict):
     """The reference's result dict.  ``image`` (H,W,3), ``depth`` (H,W) and ``nearest`` (H,W) are always
     present; ``ray_dir`` (4,N) is produced on first access.  The three O(M*N) entries of the numpy
@@ -672,8 +688,9 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     follows ``diffrend.torch.renderer.render`` instead (Phong shading with lights.attenuation / lights.ambient /
     materials.coeffs, ``double_sided``, ``use_quartic``, orthonormal camera basis, far+1 background, extra outputs
     ``normal`` and ``pos``; ``shadow=True`` adds the all-pairs shadow-ray pass and a ``light_visibility`` bit field;
-    ``camera.proj_type = 'ortho'``).  The torch backend's remaining kwargs (tiled, tile_size, ...) are accepted
-    and ignored.
+    ``camera.proj_type = 'ortho'``; ``norm_depth_image_only=True`` returns the normalised depth as ``image``).  The
+    torch backend's remaining kwargs are accepted where they change no output of the reference (``tiled``,
+    ``tile_size``, ``backface_culling`` -- see ``_TORCH_ONLY_KWARGS``); ``vis_stat=True`` raises as it does there.
     """
     unknown = set(params) - _TORCH_ONLY_KWARGS - {"device", "mode", "rows", "validate", "shading", "double_sided",
                                                   "use_quartic", "waves_per_tile"}
@@ -689,6 +706,11 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     shadow = bool(params.get("shadow", False))
     if shadow and shading != "torch":
         raise ValueError("shadow rays exist only in the torch backend's semantics: shading='torch'")
+    if params.get("vis_stat", False):
+        raise RuntimeError("Removed Support for vis_stat")          # torch/renderer.py:235, same message
+    norm_depth = bool(params.get("norm_depth_image_only", False))
+    if norm_depth and shading != "torch":
+        raise ValueError("norm_depth_image_only exists only in the torch backend's semantics: shading='torch'")
     inputs = [buf.tensors[k] for k in _float_keys(buf, shading)]
     if cam.ortho:
         if shading != "torch":
@@ -701,6 +723,8 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
         if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
             # differentiable call (no normal / pos outputs on this path)
             image, depth, nearest = _RenderFunction.apply(buf, cam, rows, mode, shade, *inputs)
+            if norm_depth:
+                image = _norm_depth_image(depth, cam.far_clip)
             return RenderResult(scene["camera"], device, image=image, depth=depth, nearest=nearest.to(torch.int64))
         width, height = frame_size(cam)
         r0, r1 = (0, height) if rows is None else rows
@@ -710,6 +734,9 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
                                                double_sided=params.get("double_sided", False),
                                                use_quartic=params.get("use_quartic", False), aux=(normal, pos),
                                                waves_per_tile=params.get("waves_per_tile", 0))
+        if norm_depth:          # torch/renderer.py:245-260 returns before the fragment stage: no normal / pos, no shadows
+            return RenderResult(scene["camera"], device, image=_norm_depth_image(depth, cam.far_clip), depth=depth,
+                                nearest=nearest.to(torch.int64))
         extra = {}
         if shadow:
             extra["light_visibility"] = shadow_pass(buf, cam, rows, image, depth, nearest, shade[1], shade[2])

@@ -624,6 +624,7 @@ def test_render_views_refuses_stream_capture():
     img = torch.empty((2, 32, 32, 3), device="cuda:0")
     dep = torch.empty((2, 32, 32), device="cuda:0")
     ws = renderer.render_views_buffers(buf, [cam, cam], img, dep)       # sizes the workspace, warms the ring
+    buf.ensure_workspace(32, 32)                                        # nothing may be allocated under capture
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(torch.cuda.Stream("cuda:0")):

@@ -125,3 +125,46 @@ def test_shadow_pass_matches_reference_torch_backend(case):
     assert same.mean() >= 0.995
     err = np.abs(res["image"].cpu().numpy() - npz["out/image"]).max(axis=-1)
     assert (err[same] > 3e-4).mean() <= 0.005, f"{(err[same] > 3e-4).mean():.3%} of pixels differ from the reference"
+
+
+def test_norm_depth_image_only_follows_the_reference_formula():
+    """torch/renderer.py:245-249.  Unpinned by a fixture (the reference's own call raises, oracle/check_ref_kwargs.py):
+    checked against the oracle's restatement of those lines applied to the oracle's depth."""
+    from surf_renderer_amd import render
+    for case in ("t2_mixed_specular_64x48", "t3_disk_cloud_64x64"):
+        scene, _, kw = load_tch_case(case)
+        far = scene["camera"]["far"]
+        want_depth = np_oracle_tch.render(scene, **kw)["depth"]
+        want = np_oracle_tch.norm_depth_image(want_depth.astype(np.float32), far)
+        res = render(scene, device="cuda:0", shading="torch", norm_depth_image_only=True, **kw)
+        torch.cuda.synchronize()
+        assert set(res.keys()) == {"image", "depth", "nearest"} and res["image"].shape == res["depth"].shape
+        got = res["image"].cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=2e-6)
+        assert got.min() == 0.0 and got.max() == 1.0
+        np.testing.assert_array_equal(got[want_depth > far] == 0.0, True)      # background sits at the minimum
+    with pytest.raises(ValueError):
+        render(scene, device="cuda:0", norm_depth_image_only=True)              # numpy semantics have no such output
+
+
+def test_torch_only_keywords_that_change_nothing_and_vis_stat():
+    from surf_renderer_amd import render
+    scene, _, kw = load_tch_case("t2_mixed_specular_64x48")
+    a = render(scene, device="cuda:0", shading="torch", **kw)
+    b = render(scene, device="cuda:0", shading="torch", backface_culling=True, tiled=True, tile_size=512, **kw)
+    for k in ("image", "depth", "nearest", "normal", "pos"):
+        assert torch.equal(a[k], b[k]), k
+    with pytest.raises(RuntimeError, match="vis_stat"):
+        render(scene, device="cuda:0", shading="torch", vis_stat=True)
+    with pytest.raises(TypeError):
+        render(scene, device="cuda:0", no_such_keyword=1)
+
+
+def test_norm_depth_image_is_differentiable_through_depth():
+    from surf_renderer_amd import render, synthetic
+    scene = synthetic.splat_basic_scene(48, 40)
+    pos = torch.tensor(np.asarray(scene["objects"]["disk"]["pos"], dtype=np.float32), device="cuda:0", requires_grad=True)
+    scene["objects"]["disk"] = dict(scene["objects"]["disk"], pos=pos)
+    res = render(scene, device="cuda:0", shading="torch", norm_depth_image_only=True)
+    res["image"].sum().backward()
+    assert pos.grad is not None and torch.isfinite(pos.grad).all() and pos.grad.abs().sum() > 0
