@@ -12,30 +12,14 @@ from __future__ import annotations
 import argparse
 import importlib
 import os
-import struct
 import sys
-import zlib
 
 import numpy as np
 
 BACKENDS = {"hip": "surf_renderer_amd.renderer", "np": "diffrend.numpy.renderer", "tch": "diffrend.torch.renderer"}
 
 
-def write_png(path: str, img: np.ndarray) -> None:
-    """Minimal 8-bit grey / RGB PNG writer (no imaging library in the image)."""
-    img = np.ascontiguousarray(img, dtype=np.uint8)
-    if img.ndim == 2:
-        img = img[..., None]
-    h, w, ch = img.shape
-    color = {1: 0, 3: 2}[ch]
-    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))
-
-    def chunk(tag: bytes, data: bytes) -> bytes:
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
-
-    with open(path, "wb") as fh:
-        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color, 0, 0, 0)) +
-                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+from .frame_writer import write_png  # noqa: E402  (shared with the asynchronous writer)
 
 
 def to_numpy(x) -> np.ndarray:
