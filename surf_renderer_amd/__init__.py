@@ -4,8 +4,9 @@
     res = render(scene)            # same scene dict as diffrend.numpy.renderer.render
     res['image'], res['depth'], res['nearest']
 """
-from .renderer import render, render_views, flatten_scene, render_buffers, camera_struct, generate_rays  # noqa: F401
+from .renderer import (render, render_views, flatten_scene, render_buffers, camera_struct, generate_rays,  # noqa: F401
+                       ResidentScene)
 from .scene import load_scene, load_model, load_obj, load_splat, obj_to_triangle_spec  # noqa: F401
 
-__all__ = ["render", "render_views", "flatten_scene", "render_buffers", "camera_struct", "generate_rays",
+__all__ = ["render", "render_views", "ResidentScene", "flatten_scene", "render_buffers", "camera_struct", "generate_rays",
            "load_scene", "load_model", "load_obj", "load_splat", "obj_to_triangle_spec"]

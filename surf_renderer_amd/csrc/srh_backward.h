@@ -6,9 +6,9 @@
 //     planar m:  n^ = n/|n|, t = n^.(q - o) / (n^.d), q = pos | face[0]          p = o + t d
 //     sphere m:  t = (-b -/+ sqrt(b^2 - 4a(|oc|^2 - r^2))) / 2a, n^ = (p - c)/|p - c|
 //     shading:   im_c = sum_i (n^ . l^_i) C_ic A_c,  l^_i = (L_i - p)/|L_i - p|;  clip at 0;  out_c = im_c ^ gamma
-// Accumulation: per-primitive gradients go out as one atomic per lane and component; light / colour gradients are
-// first summed over the wave with cross-lane shuffles (every pixel contributes to the same few addresses), and so
-// are albedo gradients when the whole wave shades with one material.
+// Accumulation: every sum is reduced over the wave before it goes out as fp32 atomics -- light / colour gradients over
+// all 64 lanes (every pixel contributes to the same few addresses), albedo gradients too when the whole wave shades
+// with one material, per-primitive gradients over the runs of adjacent pixels won by the same primitive (RunReduce).
 #pragma once
 #include "srh_device.h"
 
@@ -37,6 +37,88 @@ __device__ __forceinline__ void add3(float* dst, const double g[3]) {
   if (g[0] != 0.0) atomicAdd(dst + 0, (float)g[0]);
   if (g[1] != 0.0) atomicAdd(dst + 1, (float)g[1]);
   if (g[2] != 0.0) atomicAdd(dst + 2, (float)g[2]);
+}
+
+__device__ __forceinline__ void add3(float* dst, const float g[3]) {
+  if (g[0] != 0.0f) atomicAdd(dst + 0, g[0]);
+  if (g[1] != 0.0f) atomicAdd(dst + 1, g[1]);
+  if (g[2] != 0.0f) atomicAdd(dst + 2, g[2]);
+}
+
+// Per-primitive gradients, reduced by key over the wave before they go out as atomics.  A wave is 64 consecutive
+// pixels of one image row, so pixels won by the same primitive form RUNS of adjacent lanes: a segmented inclusive scan
+// over the runs (six shuffle steps) leaves each run's sum in its last lane, and only that lane issues the atomics --
+// one set per (wave, run) instead of one per pixel.  A plane that fills the frame sends 6 atomics per wave to its six
+// addresses instead of 384; a primitive that re-appears after a gap in the same row simply forms
+// two runs.  All 64 lanes must call this (lanes without a hit pass key -1 and zeros).
+struct RunReduce {
+  int lane, start;      // this lane, first lane of its run
+  bool tail;            // last lane of its run: holds the run's sums after reduce()
+  __device__ __forceinline__ RunReduce(int key, int lane_) : lane(lane_) {
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(head);
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));          // heads at lanes <= this one (lane 0 is one)
+    start = 63 - __builtin_clzll(upto);
+    tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+  }
+  __device__ __forceinline__ float reduce(float v) const {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float t = __shfl_up(v, off);
+      if (lane - off >= start) v += t;
+    }
+    return v;
+  }
+};
+
+// Run-reduce one pixel's primitive gradients over the wave and add the run sums: gA -> pos (disc / plane / sphere) or
+// face vertex 0 (triangle), gB -> normal (planar types), g_r -> radius (sphere).  key = winner's global index, -1 = none.
+__device__ __forceinline__ void scatter_primitive_grads(const GradsDev& G, int key, int lane, int s, int type, int li,
+                                                        const double gA[3], const double gB[3], double g_r) {
+  const RunReduce run(key, lane);
+  float v[7];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { v[k] = run.reduce((float)gA[k]); v[3 + k] = run.reduce((float)gB[k]); }
+  v[6] = run.reduce((float)g_r);
+  // Second level, for primitives larger than a wave's 64 pixels: when each of the workgroup's four waves (four image
+  // rows) is ONE run of the same primitive, wave 0 adds the four sums and issues the only atomics of the workgroup.
+  // (All 256 threads reach this barrier: the backward kernels have no early exit.)
+  __shared__ float wsum[4][8];
+  __shared__ int wkey[4];
+  const int wave = threadIdx.y;
+  const bool whole = run.start == 0 && lane == 63;          // this lane closes a run that spans the whole wave
+  if (lane == 63) {
+    wkey[wave] = (run.start == 0) ? key : -2;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wsum[wave][k] = v[k];
+  }
+  __syncthreads();
+  const bool merged = wkey[0] >= 0 && wkey[0] == wkey[1] && wkey[0] == wkey[2] && wkey[0] == wkey[3];
+  if (merged) {
+    if (!(whole && wave == 0)) return;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = (wsum[0][k] + wsum[1][k]) + (wsum[2][k] + wsum[3][k]);
+  } else if (!run.tail || key < 0) {
+    return;
+  }
+  float* dstA = nullptr;
+  float* dstB = nullptr;
+  float* dstR = nullptr;
+#pragma unroll
+  for (int i = 0; i < SRH_MAX_SEGMENTS; ++i)
+    if (s == i) {
+      dstA = type == SRH_PRIM_TRIANGLE ? (G.face[i] ? G.face[i] + 12 * (size_t)li : nullptr)
+                                       : (G.pos[i] ? G.pos[i] + 4 * (size_t)li : nullptr);
+      dstB = (type != SRH_PRIM_SPHERE && G.normal[i]) ? G.normal[i] + 4 * (size_t)li : nullptr;
+      dstR = (type == SRH_PRIM_SPHERE && G.radius[i]) ? G.radius[i] + li : nullptr;
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (dstA && v[k] != 0.0f) atomicAdd(dstA + k, v[k]);
+    if (dstB && v[3 + k] != 0.0f) atomicAdd(dstB + k, v[3 + k]);
+  }
+  if (dstR && v[6] != 0.0f) atomicAdd(dstR, v[6]);
 }
 
 __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
@@ -191,25 +273,24 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
       add3(G.albedo + 3 * m, g_alb);
     }
   }
-  if (!hit) return;                                     // no shuffles below this line
-
-  // ---- geometry ------------------------------------------------------------------------------------------------
-  if (type == SRH_PRIM_SPHERE) {
+  // ---- geometry: every lane takes part (run reduction below); lanes without a hit carry zeros -------------------------
+  double gA[3] = {0, 0, 0};        // d/d pos (disc, plane, sphere) or d/d face vertex 0 (triangle)
+  double gB[3] = {0, 0, 0};        // d/d normal (planar types)
+  double g_r = 0.0;                // d/d radius (sphere)
+  if (hit && type == SRH_PRIM_SPHERE) {
     // n^ = v/|v| with v = p - c (zero gradient where the line misses the sphere: n^ is the constant 0 there)
     const double proj = (n[0] * g_n[0] + n[1] * g_n[1]) + n[2] * g_n[2];
-    double g_c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double g_v = (g_n[k] - n[k] * proj) * sph_inv;
       g_p[k] += g_v;
-      g_c[k] = -g_v;
+      gA[k] = -g_v;
     }
     const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
     // t = (-b -/+ root)/(2a) unless it is one of the reference's constants (1.0 for a bad root, 0 for a miss)
     const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     const double b = 2.0 * dot3(R, d);
     const double disc = b * b - 4.0 * a * R[3];
-    double g_r = 0.0;
     if (disc > 0.0) {
       const double root = sqrt(disc), inv2a = 1.0 / (2.0 * a);
       const double t1 = (-b - root) * inv2a, t2 = (-b + root) * inv2a;
@@ -222,41 +303,32 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
         const double g_disc = sgn * g_t * inv2a / (2.0 * root);
         g_b += 2.0 * b * g_disc;
         const double g_cc = -4.0 * a * g_disc;
-        const float* rp = rad_base + li;
-        g_r = -2.0 * (double)rp[0] * g_cc;
+        g_r = -2.0 * (double)rad_base[li] * g_cc;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g_c[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
+        for (int k = 0; k < 3; ++k) gA[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
       }
     }
-    if (G.pos[s]) add3(G.pos[s] + 4 * (size_t)li, g_c);
-    if (G.radius[s] && g_r != 0.0) atomicAdd(G.radius[s] + li, (float)g_r);
-    return;
-  }
-  // planar: t = k/den, k = n^.(q - o), den = n^.d
-  const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
-  const double den = dot3(R, d);
-  const double g_k = g_t / den, g_den = -g_t * t / den;
-  const float* qp = (type == SRH_PRIM_TRIANGLE) ? face_base + 12 * (size_t)li : pos_base + 4 * (size_t)li;
-  double g_q[3], g_nh[3];
+  } else if (hit) {
+    // planar: t = k/den, k = n^.(q - o), den = n^.d
+    const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
+    const double den = dot3(R, d);
+    const double g_k = g_t / den, g_den = -g_t * t / den;
+    const float* qp = (type == SRH_PRIM_TRIANGLE) ? face_base + 12 * (size_t)li : pos_base + 4 * (size_t)li;
+    double g_nh[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    g_q[k] = g_k * n[k];
-    g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
-  }
-  // n^ = nin/|nin| (4-D norm with w = 0; a zero normal stays zero and gets the gradient divided by 1)
-  const float* np_ = nrm_base + 4 * (size_t)li;
-  const double nin2 = (((double)np_[0] * np_[0] + (double)np_[1] * np_[1]) + (double)np_[2] * np_[2]) + (double)np_[3] * np_[3];
-  const double ninv = (nin2 > 0.0) ? 1.0 / sqrt(nin2) : 1.0;
-  const double proj = (nin2 > 0.0) ? (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2] : 0.0;
-  double g_nin[3];
+    for (int k = 0; k < 3; ++k) {
+      gA[k] = g_k * n[k];
+      g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
+    }
+    // n^ = nin/|nin| (4-D norm with w = 0; a zero normal stays zero and gets the gradient divided by 1)
+    const float* np_ = nrm_base + 4 * (size_t)li;
+    const double nin2 = (((double)np_[0] * np_[0] + (double)np_[1] * np_[1]) + (double)np_[2] * np_[2]) + (double)np_[3] * np_[3];
+    const double ninv = (nin2 > 0.0) ? 1.0 / sqrt(nin2) : 1.0;
+    const double proj = (nin2 > 0.0) ? (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) g_nin[k] = (g_nh[k] - n[k] * proj) * ninv;
-  if (type == SRH_PRIM_TRIANGLE) {
-    if (G.face[s]) add3(G.face[s] + 12 * (size_t)li, g_q);
-  } else if (G.pos[s]) {
-    add3(G.pos[s] + 4 * (size_t)li, g_q);
+    for (int k = 0; k < 3; ++k) gB[k] = (g_nh[k] - n[k] * proj) * ninv;
   }
-  if (G.normal[s]) add3(G.normal[s] + 4 * (size_t)li, g_nin);
+  scatter_primitive_grads(G, hit ? win : -1, lane, s, type, li, gA, gB, g_r);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -270,7 +342,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
 // multiply) and the nearest-hit selection.  torch.pow: 0^0 = 1, d/d exponent = 0 at base 0, d/d base = 0 at exponent 0.
 // Misses and the far + 1 background carry no gradient.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
                                                          const float* __restrict__ grad_depth,
                                                          const int32_t* __restrict__ nearest,
                                                          const float* __restrict__ depth,
@@ -283,7 +355,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
   const int cc = live ? c : 0;
   const bool hit = live && ((double)depth[row * F.depth_stride + cc] <= F.far_clip);
 
-  double g_out[3] = {0, 0, 0}, g_dep = 0.0;
+  float g_out[3] = {0, 0, 0}, g_dep = 0.0f;               // upstream gradients are fp32
   int win = 0;
   if (hit) {
     const float* gi = grad_image + row * F.img_stride + 3 * (size_t)cc;
@@ -295,20 +367,21 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
 #pragma unroll
   for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
     if (i < F.nseg && win >= F.seg[i].first) s = i;
+  // only what the whole kernel needs stays in registers (type, local index, record); the other per-segment pointers are
+  // selected again where they are used -- six 64-bit pointers held across both light loops cost 12 registers
   int type = F.seg[0].type, first = F.seg[0].first;
   const double* rec_base = F.seg[0].rec64;
-  const float* pos_base = F.seg[0].pos;
-  const float* nrm_base = F.seg[0].normal;
-  const float* rad_base = F.seg[0].radius;
-  const float* face_base = F.seg[0].face;
-  const int32_t* mat_base = F.seg[0].mat;
 #pragma unroll
   for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
-    if (s == i) {
-      type = F.seg[i].type; first = F.seg[i].first; rec_base = F.seg[i].rec64; pos_base = F.seg[i].pos;
-      nrm_base = F.seg[i].normal; rad_base = F.seg[i].radius; face_base = F.seg[i].face; mat_base = F.seg[i].mat;
-    }
+    if (s == i) { type = F.seg[i].type; first = F.seg[i].first; rec_base = F.seg[i].rec64; }
   const int li = win - first;
+  auto seg_ptr = [&](auto field) {
+    auto ptr = field(F.seg[0]);
+#pragma unroll
+    for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+      if (s == i) ptr = field(F.seg[i]);
+    return ptr;
+  };
   // light visibility of the forward pass (shadow rays): a constant 0 / 1 factor on each light's colour x albedo term
   const uint64_t vis = (visibility && hit) ? visibility[row * (size_t)F.W + cc] : ~0ull;
 
@@ -324,7 +397,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
 #pragma unroll
     for (int k = 0; k < 3; ++k) p[k] = F.o[k] + t * d[k];
     if (type == SRH_PRIM_SPHERE) {
-      const float* cp = pos_base + 4 * (size_t)li;
+      const float* cp = seg_ptr([](const SegDev& S) { return S.pos; }) + 4 * (size_t)li;
       double v[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) v[k] = p[k] - (double)cp[k];
@@ -335,8 +408,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
       n[0] = R[0]; n[1] = R[1]; n[2] = R[2];
     }
   }
-  const int m = hit ? clampi(mat_base[li], 0, F.nmat - 1) : 0;
-  double alb[3] = {0, 0, 0}, cf[3] = {1.0, 0.0, 0.0}, amb[3] = {0, 0, 0};
+  const int m = hit ? clampi(seg_ptr([](const SegDev& S) { return S.mat; })[li], 0, F.nmat - 1) : 0;
+  float alb[3] = {0, 0, 0}, cf[3] = {1.0f, 0.0f, 0.0f}, amb[3] = {0, 0, 0};    // inputs are fp32: kept as such, widened at use
   if (hit) {
     alb[0] = F.albedo[3 * m]; alb[1] = F.albedo[3 * m + 1]; alb[2] = F.albedo[3 * m + 2];
     if (F.coeffs) { cf[0] = F.coeffs[3 * m]; cf[1] = F.coeffs[3 * m + 1]; cf[2] = F.coeffs[3 * m + 2]; }
@@ -374,7 +447,9 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
     T.nd = sgn * (T.afac * T.ldn);
     T.rd = sgn * (2.0 * T.ldn * cdotn - T.cl);
   };
-  auto spec_pow = [&](double rdotc) { return (rdotc == 0.0 && cf[2] == 0.0) ? 1.0 : pow(rdotc, cf[2]); };
+  // powers and logarithms in fp32 (a library pow in fp64 alone holds ~60 registers): the forward pass evaluates the
+  // lobe in fp32 too (spec_pow_f32), and the sums these terms enter leave as fp32 atomics
+  auto spec_pow = [&](double rdotc) { return (rdotc == 0.0 && cf[2] == 0.0) ? 1.0 : (double)powf((float)rdotc, (float)cf[2]); };
 
   double im[3] = {0, 0, 0};
   for (int l = 0; l < F.nlights; ++l) {
@@ -389,11 +464,12 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     double w = 0.0;
-    if (hit && im[ch] > 0.0) w = F.tonemap ? F.gamma * pow(im[ch], F.gamma - 1.0) : 1.0;
+    if (hit && im[ch] > 0.0) w = F.tonemap ? F.gamma * (double)powf((float)im[ch], (float)(F.gamma - 1.0)) : 1.0;
     g_im[ch] = g_out[ch] * w;
   }
 
-  double g_n[3] = {0, 0, 0}, g_p[3] = {0, 0, 0}, g_alb[3] = {0, 0, 0}, g_cf[3] = {0, 0, 0}, g_amb[3] = {0, 0, 0};
+  double g_n[3] = {0, 0, 0}, g_p[3] = {0, 0, 0};
+  float g_alb[3] = {0, 0, 0}, g_cf[3] = {0, 0, 0}, g_amb[3] = {0, 0, 0};     // leave as fp32 atomics: summed in fp32
   double g_cdir[3] = {0, 0, 0}, g_cdotn = 0.0;
   for (int l = 0; l < F.nlights; ++l) {
     LightTerms T;
@@ -408,16 +484,16 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
     for (int ch = 0; ch < 3; ++ch) {
       const double col = (double)F.colors[3 * ci + ch];
       g_w += g_im[ch] * col * alb[ch];
-      g_alb[ch] += g_im[ch] * (w * col + amb[ch]);
+      g_alb[ch] += (float)(g_im[ch] * (w * col + amb[ch]));
       g_col[ch] = g_im[ch] * w * alb[ch];
-      g_amb[ch] += g_im[ch] * alb[ch];
+      g_amb[ch] += (float)(g_im[ch] * alb[ch]);
     }
     g_w *= vl;                                                  // d im / d (unshadowed weight)
-    g_cf[0] += g_w * ndotl;
-    g_cf[1] += g_w * P;
-    if (rdotc > 0.0) g_cf[2] += g_w * cf[1] * P * log(rdotc);
+    g_cf[0] += (float)(g_w * ndotl);
+    g_cf[1] += (float)(g_w * P);
+    if (rdotc > 0.0) g_cf[2] += (float)(g_w * cf[1] * P) * logf((float)rdotc);
     const double g_nd = (T.nd > 0.0) ? g_w * cf[0] : 0.0;
-    const double g_rd = (T.rd > 0.0 && cf[2] != 0.0) ? g_w * cf[1] * cf[2] * pow(rdotc, cf[2] - 1.0) : 0.0;
+    const double g_rd = (T.rd > 0.0 && cf[2] != 0.0) ? g_w * cf[1] * cf[2] * (double)powf((float)rdotc, (float)(cf[2] - 1.0)) : 0.0;
     double g_ldn = g_rd * sgn * 2.0 * cdotn + g_nd * sgn * T.afac;
     g_cdotn += g_rd * sgn * 2.0 * T.ldn;
     const double g_cl = -g_rd * sgn;
@@ -498,32 +574,28 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
       }
     }
   }
-  if (!hit) return;                                     // no shuffles below this line
-
-  // c^ . n^ and c^ = u / sqrt(|u|^2 + eps), u = o - p
+  // ---- view direction and geometry: every lane takes part (run reduction below); lanes without a hit carry zeros ------
+  double gA[3] = {0, 0, 0}, gB[3] = {0, 0, 0}, g_r = 0.0;
+  if (hit) {
+    // c^ . n^ and c^ = u / sqrt(|u|^2 + eps), u = o - p
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { g_cdir[k] += g_cdotn * n[k]; g_n[k] += g_cdotn * cdir[k]; }
-  {
-    const double proj = (cdir[0] * g_cdir[0] + cdir[1] * g_cdir[1]) + cdir[2] * g_cdir[2];
+    for (int k = 0; k < 3; ++k) { g_cdir[k] += g_cdotn * n[k]; g_n[k] += g_cdotn * cdir[k]; }
+    const double projc = (cdir[0] * g_cdir[0] + cdir[1] * g_cdir[1]) + cdir[2] * g_cdir[2];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_p[k] -= (g_cdir[k] - cdir[k] * proj) * sc_inv;
+    for (int k = 0; k < 3; ++k) g_p[k] -= (g_cdir[k] - cdir[k] * projc) * sc_inv;
   }
-
-  // ---- geometry ------------------------------------------------------------------------------------------------
-  if (type == SRH_PRIM_SPHERE) {
+  if (hit && type == SRH_PRIM_SPHERE) {
     const double proj = (n[0] * g_n[0] + n[1] * g_n[1]) + n[2] * g_n[2];
-    double g_c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double g_v = (g_n[k] - n[k] * proj) * sph_inv;
       g_p[k] += g_v;
-      g_c[k] = -g_v;
+      gA[k] = -g_v;
     }
     const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
     const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     const double b = 2.0 * dot3(R, d);
     const double disc = b * b - 4.0 * a * R[3];
-    double g_r = 0.0;
     if (disc > 0.0) {
       const double root = sqrt(disc), inv2a = 1.0 / (2.0 * a);
       const double t1 = (-b - root) * inv2a;
@@ -532,39 +604,32 @@ __global__ __launch_bounds__(256) void k_render_bwd_tch(FrameDev F, GradsDev G, 
       const double g_disc = sg * g_t * inv2a / (2.0 * root);
       g_b += 2.0 * b * g_disc;
       const double g_cc = -4.0 * a * g_disc;
-      g_r = -2.0 * (double)rad_base[li] * g_cc;
+      g_r = -2.0 * (double)seg_ptr([](const SegDev& S) { return S.radius; })[li] * g_cc;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) g_c[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
+      for (int k = 0; k < 3; ++k) gA[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
     }
-    if (G.pos[s]) add3(G.pos[s] + 4 * (size_t)li, g_c);
-    if (G.radius[s] && g_r != 0.0) atomicAdd(G.radius[s] + li, (float)g_r);
-    return;
-  }
-  // planar: t = k/den, k = n^.(q - o), den = n^.d
-  const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
-  const double den = dot3(R, d);
-  const double g_k = g_t / den, g_den = -g_t * t / den;
-  const float* qp = (type == SRH_PRIM_TRIANGLE) ? face_base + 12 * (size_t)li : pos_base + 4 * (size_t)li;
-  double g_q[3], g_nh[3];
+  } else if (hit) {
+    // planar: t = k/den, k = n^.(q - o), den = n^.d
+    const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
+    const double den = dot3(R, d);
+    const double g_k = g_t / den, g_den = -g_t * t / den;
+    const float* qp = (type == SRH_PRIM_TRIANGLE) ? seg_ptr([](const SegDev& S) { return S.face; }) + 12 * (size_t)li
+                                                  : seg_ptr([](const SegDev& S) { return S.pos; }) + 4 * (size_t)li;
+    double g_nh[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    g_q[k] = g_k * n[k];
-    g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
-  }
-  // n^ = nin / sqrt(|nin|^2 + 3e-10) over xyz
-  const float* np_ = nrm_base + 4 * (size_t)li;
-  const double nin2 = (((double)np_[0] * np_[0] + 1e-10) + ((double)np_[1] * np_[1] + 1e-10)) + ((double)np_[2] * np_[2] + 1e-10);
-  const double ninv = 1.0 / sqrt(nin2);
-  const double proj = (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2];
-  double g_nin[3];
+    for (int k = 0; k < 3; ++k) {
+      gA[k] = g_k * n[k];
+      g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
+    }
+    // n^ = nin / sqrt(|nin|^2 + 3e-10) over xyz
+    const float* np_ = seg_ptr([](const SegDev& S) { return S.normal; }) + 4 * (size_t)li;
+    const double nin2 = (((double)np_[0] * np_[0] + 1e-10) + ((double)np_[1] * np_[1] + 1e-10)) + ((double)np_[2] * np_[2] + 1e-10);
+    const double ninv = 1.0 / sqrt(nin2);
+    const double proj = (n[0] * g_nh[0] + n[1] * g_nh[1]) + n[2] * g_nh[2];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) g_nin[k] = (g_nh[k] - n[k] * proj) * ninv;
-  if (type == SRH_PRIM_TRIANGLE) {
-    if (G.face[s]) add3(G.face[s] + 12 * (size_t)li, g_q);
-  } else if (G.pos[s]) {
-    add3(G.pos[s] + 4 * (size_t)li, g_q);
+    for (int k = 0; k < 3; ++k) gB[k] = (g_nh[k] - n[k] * proj) * ninv;
   }
-  if (G.normal[s]) add3(G.normal[s] + 4 * (size_t)li, g_nin);
+  scatter_primitive_grads(G, hit ? win : -1, lane, s, type, li, gA, gB, g_r);
 }
 
 }  // namespace srh

@@ -632,6 +632,48 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     return out
 
 
+class ResidentScene:
+    """A scene flattened ONCE and rendered many times -- the shape of an optimisation loop
+    (diffrend/torch/test_optimization.py: render, loss, backward, optimiser step, repeat).  ``render(scene)`` pays the
+    scene conversion, validation and descriptor building on every call (about as long as the GPU work for a mesh of a
+    few thousand triangles); here that happens in the constructor.  Leaves that are contiguous float32 tensors on the
+    render device are used IN PLACE: an optimiser that updates them in place (torch.optim does) is seen by the next
+    ``render()`` without any copy, and their ``.grad`` is filled by the analytic HIP backward.  ``nearest`` comes back
+    as the kernel writes it (int32; ``render(scene)`` widens it to the reference's int64 with one more pass).
+
+        rs = ResidentScene(scene, shading='torch')        # leaves with requires_grad=True stay attached
+        for _ in range(steps):
+            opt.zero_grad(); loss(rs.render()['image']).backward(); opt.step()
+    """
+
+    def __init__(self, scene: Dict[str, Any], device="cuda", shading: str = "numpy", mode: str = "auto",
+                 double_sided: bool = False, use_quartic: bool = False, validate: bool = True):
+        if shading not in _lib.SHADING:
+            raise ValueError(f"shading must be 'numpy' or 'torch', got {shading!r}")
+        self.device = torch.device(device)
+        self.buf = flatten_scene(scene, self.device, validate=validate, keep_graph=True)
+        self.shading, self.mode = shading, mode
+        self._camera = scene["camera"]
+        self.cam = camera_struct(scene["camera"], shading)
+        if self.cam.ortho:
+            raise NotImplementedError("ResidentScene renders perspective cameras (orthographic frames are forward only)")
+        self.shade = (shading, bool(double_sided), bool(use_quartic), False)
+        self.inputs = [self.buf.tensors[k] for k in _float_keys(self.buf, shading)]
+        self.differentiable = any(t.requires_grad for t in self.inputs)
+
+    def set_camera(self, camera: Dict[str, Any]) -> None:
+        self._camera = camera
+        self.cam = camera_struct(camera, self.shading)
+
+    def render(self, rows: Optional[Tuple[int, int]] = None) -> "RenderResult":
+        if self.differentiable and torch.is_grad_enabled():
+            image, depth, nearest = _RenderFunction.apply(self.buf, self.cam, rows, self.mode, self.shade, *self.inputs)
+        else:
+            image, depth, nearest = render_buffers(self.buf, self.cam, rows=rows, mode=self.mode, shading=self.shading,
+                                                   double_sided=self.shade[1], use_quartic=self.shade[2])
+        return RenderResult(self._camera, self.device, image=image, depth=depth, nearest=nearest)
+
+
 def _norm_depth_image(depth: torch.Tensor, far: float) -> torch.Tensor:
     """`norm_depth_image_only` of the torch backend (torch/renderer.py:245-249), on the far + 1 background depth:
     background pixels take the minimum depth, then (d - min) / (max - min) -- the same tensor expression, so it is

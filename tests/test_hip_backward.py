@@ -263,3 +263,35 @@ def test_fuzz_backward_against_the_gradient_oracles():
         got = {k: (t.grad.cpu().numpy().astype(np.float64) if t.grad is not None else np.zeros(tuple(t.shape)))
                for k, t in leaves.items()}
         compare(f"scene {done} torch {kw} shadow={shadow}", got, want, 5e-3 if shadow else 5e-4)
+
+
+def test_resident_scene_matches_render_and_sees_in_place_updates():
+    """ResidentScene flattens once: same outputs and gradients as render(scene), and an in-place update of a leaf
+    (what torch.optim does) is what the next render() sees."""
+    import torch
+    from surf_renderer_amd import ResidentScene, render, synthetic
+    scene = synthetic.demo_scene(72, 56, with_planes=True)
+    pos = torch.tensor(np.asarray(scene["objects"]["disk"]["pos"], dtype=np.float32), device="cuda:0", requires_grad=True)
+    nrm = torch.tensor(np.asarray(scene["objects"]["disk"]["normal"], dtype=np.float32), device="cuda:0", requires_grad=True)
+    scene["objects"]["disk"] = dict(scene["objects"]["disk"], pos=pos, normal=nrm)
+
+    def loss(res):
+        return (res["image"] ** 2).sum() + 0.1 * res["depth"].clamp(max=50.0).sum()
+
+    a = render(scene, device="cuda:0")
+    loss(a).backward()
+    want = (pos.grad.clone(), nrm.grad.clone())
+    pos.grad = None
+    nrm.grad = None
+    rs = ResidentScene(scene, device="cuda:0")
+    b = rs.render()
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
+    assert torch.equal(a["nearest"], b["nearest"].to(torch.int64))
+    loss(b).backward()
+    torch.testing.assert_close(pos.grad, want[0], rtol=1e-4, atol=1e-6 * float(want[0].abs().max()))
+    torch.testing.assert_close(nrm.grad, want[1], rtol=1e-4, atol=1e-6 * float(want[1].abs().max()))
+    with torch.no_grad():
+        pos[:, 2] += 0.25                                # in place, as an optimiser step
+    c = rs.render()
+    d = render(scene, device="cuda:0")
+    assert torch.equal(c["image"], d["image"]) and not torch.equal(c["image"], a["image"])

@@ -82,6 +82,19 @@ def main():
             dt = fwd_bwd(sc, ps, args.steps, **kw)
             out = {"case": case, "what": "bunny.obj 1024x1024 forward + backward through render()", "ms_per_iteration": 1e3 * dt,
                    "iterations_per_s": 1 / dt}
+        elif case in ("bwd_mesh_resident", "bwd_mesh_resident_tch"):
+            sc = synthetic.bunny_mesh_scene(1024, 1024)
+            ps = leaves(sc, "triangle", ("face", "normal"))
+            rs = renderer.ResidentScene(sc, device=DEV, shading="torch" if case.endswith("tch") else "numpy", validate=False)
+
+            def it():
+                for p_ in ps:
+                    p_.grad = None
+                res = rs.render()
+                (res["image"].sum() + res["depth"].clamp(max=100.0).sum()).backward()
+            dt = timed(it, args.steps * 5, 5)
+            out = {"case": case, "what": "bunny.obj 1024x1024 forward + backward, ResidentScene (scene flattened once)",
+                   "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt}
         elif case == "bwd_plane":
             sc = plane_scene(2048, 2048)
             ps = leaves(sc, "plane", ("pos", "normal"))
