@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 8
+#define SRH_ABI_VERSION 9
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -226,7 +226,12 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
  * srh_render_fwd with the same camera / scene / params (SRH_SHADING_TORCH): per hit pixel and light a shadow ray from
  * the fragment (started 0.1 towards the light) against every primitive, all pairs in fp64; a light is visible unless
  * a primitive other than the fragment's own is hit before it.  `image` (rows,W,3) is overwritten with the re-shaded
- * frame; `visibility` (rows,W) uint64, bit l = light l visible, may be NULL.  O(pixels x lights x primitives). */
+ * frame; `visibility` (rows,W) uint64, bit l = light l visible, may be NULL.
+ * With a workspace of srh_shadow_workspace_bytes(...) bytes the candidates of a shadow ray come from tile bins built
+ * in each light's own screen space (every candidate still goes through the same fp64 test, so the result equals the
+ * all-pairs pass bit for bit); with the smaller srh_workspace_bytes(...) workspace, or params->mode =
+ * SRH_MODE_EXACT, the pass is the reference's O(pixels x lights x primitives) loop. */
+size_t srh_shadow_workspace_bytes(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_lights);
 int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
                      const int32_t* nearest, const float* depth, float* image, uint64_t* visibility, void* stream);

@@ -8,7 +8,7 @@ from typing import Optional
 
 from . import build as _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_SEGMENTS = 4
 MAX_LIGHTS = 64
 
@@ -69,6 +69,7 @@ class SrhGrads(C.Structure):
 
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
            "srh_render_bwd", "srh_workspace_bytes_views", "srh_render_views", "srh_shadow_shade",
+           "srh_shadow_workspace_bytes",
            "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
@@ -121,6 +122,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_render_views.argtypes = [C.c_int32, C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                      C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srh_shadow_workspace_bytes.restype = C.c_size_t
+    lib.srh_shadow_workspace_bytes.argtypes = [C.POINTER(SrhObjects), C.c_int32, C.c_int32, C.c_int32]
     lib.srh_shadow_shade.restype = C.c_int
     lib.srh_shadow_shade.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                      C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,

@@ -20,6 +20,7 @@
 #include "srh_reject.h"
 #include "srh_binned.h"
 #include "srh_backward.h"
+#include "srh_shadow.h"
 
 using namespace srh;
 
@@ -120,7 +121,29 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
     case SRH_PRIM_TRIANGLE: triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q); break;
     default: plane_reject_record(R, B, F.W, F.H, Q); break;
   }
-  if (F.tilerange) bin_primitive(F, s, S.type, Q, S.first + i);
+  if (F.tilerange) {
+    // light views: a primitive that comes within near_ball of the eye can block a shadow ray from BEHIND the light
+    // (the reference accepts hits up to 0.1 beyond it); its screen-space shape says nothing about that, so every
+    // query tests it
+    bool near_eye = false;
+    if (F.near_ball > 0.0) {
+      double dmin = 0.0;
+      if (S.type == SRH_PRIM_DISK) dmin = sqrt(dot3(R + 4, R + 4)) - sqrt(fabs(R[7]));
+      else if (S.type == SRH_PRIM_SPHERE) dmin = sqrt(dot3(R, R)) - sqrt(fabs(dot3(R, R) - R[3]));
+      else if (S.type == SRH_PRIM_TRIANGLE) {
+        double far2 = 0.0, near2 = 1.0e300;
+        for (int v = 0; v < 3; ++v) {
+          const double w[3] = {R[4 + 3 * v] - F.o[0], R[5 + 3 * v] - F.o[1], R[6 + 3 * v] - F.o[2]};
+          near2 = fmin(near2, dot3(w, w));
+          const double* e = R + 13 + 3 * v;
+          far2 = fmax(far2, dot3(e, e));
+        }
+        dmin = sqrt(near2) - sqrt(far2);                        // every point is within one edge length of a vertex
+      }
+      near_eye = !(dmin > F.near_ball);                         // NaN -> large
+    }
+    bin_primitive(F, s, S.type, Q, S.first + i, near_eye);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
@@ -927,6 +950,35 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   return e == hipSuccess ? SRH_OK : hip_fail(e, "views launch");
 }
 
+namespace {
+// Workspace of the accelerated shadow pass: the primary frame's layout first (so a workspace sized by
+// srh_workspace_bytes still serves the all-pairs fallback), then the light views' frame descriptors, the scene bounds,
+// and one kShadowRes^2 binning slice per light.
+struct ShadowLayout {
+  WsLayout primary, slice;
+  size_t frames, bounds, slices, total;
+};
+ShadowLayout shadow_layout_for(const SrhObjects* ob, int width, int height, int n_lights) {
+  ShadowLayout S;
+  S.primary = layout_for(ob, width, height);
+  S.slice = layout_for(ob, kShadowRes, kShadowRes);
+  size_t off = S.primary.total;
+  S.frames = off;
+  off = align_up(off + (size_t)SRH_MAX_LIGHTS * sizeof(FrameDev));
+  S.bounds = off;
+  off = align_up(off + 64 * sizeof(int));
+  S.slices = off;
+  S.total = off + (size_t)(n_lights > 0 ? n_lights : 0) * S.slice.total;
+  return S;
+}
+}  // namespace
+
+size_t srh_shadow_workspace_bytes(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_lights) {
+  if (!srh_workspace_bytes(objects, width, height)) return 0;        // validates, leaves the message
+  if (n_lights < 0 || n_lights > SRH_MAX_LIGHTS) { fail(SRH_E_RANGE, "n_lights = %d, expected 0..%d", n_lights, SRH_MAX_LIGHTS); return 0; }
+  return shadow_layout_for(objects, width, height, n_lights).total;
+}
+
 int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const SrhLights* lights,
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
                      const int32_t* nearest, const float* depth, float* image, uint64_t* visibility, void* stream) {
@@ -944,7 +996,53 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
     hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
-  hipLaunchKernelGGL(k_shadow_shade, grid, block, 0, st, F, image, depth, nearest, visibility);
+  const ShadowLayout SL = shadow_layout_for(objects, F.W, F.H, F.nlights);
+  const bool accelerated = params->mode != SRH_MODE_EXACT && F.nlights > 0 && workspace_bytes >= SL.total;
+  if (!accelerated) {
+    // all pairs (mode = SRH_MODE_EXACT asks for it; a workspace sized by srh_workspace_bytes has no room for the views)
+    hipLaunchKernelGGL(k_shadow_shade, grid, block, 0, st, F, image, depth, nearest, visibility);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SRH_OK : hip_fail(e, "shadow launch");
+  }
+  char* ws = (char*)workspace;
+  FrameDev* frames = (FrameDev*)(ws + SL.frames);
+  int* bounds = (int*)(ws + SL.bounds);
+  // template of a light view: the primary frame's inputs and shading, a kShadowRes^2 viewport, slice 0's pointers
+  FrameDev T = F;
+  {
+    SrhCamera dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    dummy.eye[2] = 1.0; dummy.eye[3] = 1.0; dummy.at[3] = 1.0; dummy.up[1] = 1.0;
+    dummy.fovy = 1.5707963267948966; dummy.focal_length = 1.0; dummy.near_clip = 1.0e-300; dummy.far_clip = 1.0e300;
+    dummy.viewport[2] = kShadowRes; dummy.viewport[3] = kShadowRes;
+    if ((rc = camera_to_frame(&dummy, &T, true))) return rc;
+  }
+  T.row0 = 0;
+  T.row1 = kShadowRes;
+  T.normal_out = nullptr;
+  T.pos_out = nullptr;
+  char* slice0 = ws + SL.slices;
+  T.lights64 = (const double*)(slice0 + SL.slice.lights64);
+  for (int s = 0; s < T.nseg; ++s) {
+    T.seg[s].rec64 = (const double*)(slice0 + SL.slice.off64[s]);
+    T.seg[s].rec32 = (const float*)(slice0 + SL.slice.off32[s]);
+  }
+  setup_binning(T, SL.slice, slice0);
+  T.bin_pad = 1.0;              // shadow rays cross the image plane between pixel centres
+  T.near_ball = 0.1001;         // occluders up to 0.1 behind the light count (torch/renderer.py:299-306)
+  const unsigned V = (unsigned)F.nlights;
+  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, st, bounds);
+  for (int s = 0; s < F.nseg; ++s)
+    hipLaunchKernelGGL(k_scene_bounds, dim3((F.seg[s].count + 255) / 256), dim3(256), 0, st, F, s, bounds);
+  hipLaunchKernelGGL(k_light_frames, dim3((V + 63) / 64), dim3(64), 0, st, T, F.lpos, F.nlights, bounds, frames, SL.slice.total);
+  const size_t ncount = (size_t)kCounterPad + 2 * (size_t)T.nbins;
+  hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);
+  for (int s = 0; s < T.nseg; ++s)
+    hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + 255) / 256, V), dim3(256), 0, st, frames, s);
+  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + 255) / 256), V), dim3(256), 0, st, frames);
+  hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, frames);
+  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)T.total * kFillLanes + 255) / 256), V), dim3(256), 0, st, frames);
+  hipLaunchKernelGGL(k_shadow_shade_binned, grid, block, 0, st, F, frames, image, depth, nearest, visibility);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "shadow launch");
 }

@@ -29,9 +29,11 @@ __device__ __forceinline__ int segment_of(const FrameDev& F, int gidx) {
 }
 
 // ---- tile range of one primitive (called from k_prep) ------------------------------------------------
-__device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const float* rec32, int gidx) {
+__device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const float* rec32, int gidx,
+                                     bool force_large = false) {
   BBox b = bbox_full();
-  if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) b = conic_bbox(rec32);
+  if (force_large) { /* keep the full box */ }
+  else if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) b = conic_bbox(rec32);
   else if (type == SRH_PRIM_TRIANGLE) b = triangle_bbox(rec32);
   uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
   tr[0] = 1; tr[1] = 0; tr[2] = 0; tr[3] = 0;                    // default: not binned
@@ -89,8 +91,9 @@ __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
   uint64_t mask = 0;
   for (int k = sub; k < n; k += kCountLanes) {
     const int tx = tx0 + k % nx, ty = ty0 + k / nx;
-    const double pc0 = tx * kTile, pr0 = F.row0 + ty * kTile;
-    const double pc1 = fmin(pc0 + kTile - 1, (double)(F.W - 1)), pr1 = fmin(pr0 + kTile - 1, (double)(F.row1 - 1));
+    const double pc0 = tx * kTile - F.bin_pad, pr0 = F.row0 + ty * kTile - F.bin_pad;
+    const double pc1 = fmin(tx * kTile + kTile - 1, (double)(F.W - 1)) + F.bin_pad;
+    const double pr1 = fmin(F.row0 + ty * kTile + kTile - 1, (double)(F.row1 - 1)) + F.bin_pad;
     if (T.reaches(pc0, pc1, pr0, pr1)) {
       mask |= 1ull << k;
       atomicAdd(&count[ty * F.tiles_x + tx], 1u);

@@ -65,6 +65,11 @@ struct FrameDev {
   uint32_t* tile_off;                // (nbins+1) exclusive prefix of the bin counts
   uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)
   uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by bin
+  // Light views of the shadow pass (srh_shadow.h): bins are queried at CONTINUOUS positions, so a tile's rectangle grows
+  // by bin_pad pixels on every side (0 for pixel-centre rendering), and primitives within near_ball of the eye go to
+  // the `large` lists (every query tests them).  view_valid = 0: this light has no usable view (all-pairs fallback).
+  double bin_pad, near_ball;
+  int32_t view_valid, pad5;
   SegDev seg[SRH_MAX_SEGMENTS];
   const double* lights64;            // (nlights,6) per-frame fp64 copy written by k_prep: position xyz, colour rgb
   const float* lpos;

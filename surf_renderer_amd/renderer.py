@@ -123,6 +123,7 @@ class SceneBuffers:
     workspace: Optional[torch.Tensor] = None   # per-frame scratch, sized for the largest frame seen so far
     workspace_frame: Tuple[int, int] = (0, 0)
     total: int = 0
+    shadow_workspace: Optional[torch.Tensor] = None   # scratch of the accelerated shadow pass (light views)
 
     def ensure_workspace(self, width: int, height: int) -> torch.Tensor:
         """Device scratch for libsrh (primitive records + tile bins) at ``width x height``."""
@@ -420,19 +421,30 @@ def _float_keys(buf: SceneBuffers, shading: str = "numpy") -> List[str]:
 
 
 def shadow_pass(buf: SceneBuffers, cam: _lib.SrhCamera, rows, image: torch.Tensor, depth: torch.Tensor,
-                nearest: torch.Tensor, double_sided: bool = False, use_quartic: bool = False) -> torch.Tensor:
+                nearest: torch.Tensor, double_sided: bool = False, use_quartic: bool = False,
+                all_pairs: bool = False) -> torch.Tensor:
     """The torch backend's ``shadow=True`` (torch/renderer.py:291-314) over a frame rendered with
-    ``shading='torch'``: re-shades ``image`` in place with per-light visibility from all-pairs shadow rays and returns
-    the (rows, W) int64 visibility bit field (bit l = light l visible)."""
+    ``shading='torch'``: re-shades ``image`` in place with per-light visibility from shadow rays and returns the
+    (rows, W) int64 visibility bit field (bit l = light l visible).  Candidates come from tile bins in each light's
+    screen space; ``all_pairs=True`` runs the reference's O(pixels x lights x primitives) loop instead (same result)."""
     lib = _lib.load()
     width, height = frame_size(cam)
     r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
     vis = torch.empty((r1 - r0, width), dtype=torch.int64, device=buf.device)
-    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES["auto"],
+    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES["exact" if all_pairs else "auto"],
                             tonemap_gamma=0 if buf.gamma is None else 1,
                             gamma=1.0 if buf.gamma is None else buf.gamma, shading=_lib.SHADING["torch"],
                             double_sided=int(bool(double_sided)), use_quartic=int(bool(use_quartic)))
-    workspace = buf.ensure_workspace(width, height)
+    if all_pairs:
+        workspace = buf.ensure_workspace(width, height)
+    else:
+        # room for the light views (tile bins in every light's screen space) behind the primary frame's scratch
+        need = lib.srh_shadow_workspace_bytes(C.byref(buf.objects), width, height, buf.lights.n_lights)
+        if need == 0:
+            raise _lib.SrhError(-2, lib.srh_last_error().decode())
+        if buf.shadow_workspace is None or buf.shadow_workspace.numel() < need:
+            buf.shadow_workspace = torch.empty(need, dtype=torch.uint8, device=buf.device)
+        workspace = buf.shadow_workspace
     with torch.cuda.device(buf.device):
         _lib.check(lib.srh_shadow_shade(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                         C.byref(params), workspace.data_ptr(), workspace.numel(), nearest.data_ptr(),

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import np_oracle_tch
-from test_oracle_tch import CASES, assert_tch_parity, load_tch_case
+from test_oracle_tch import CASES, assert_tch_parity, load_shadow_case, load_tch_case
 
 pytestmark = pytest.mark.gpu
 
@@ -170,3 +170,90 @@ def test_norm_depth_image_is_differentiable_through_depth():
     res = render(scene, device="cuda:0", shading="torch", norm_depth_image_only=True)
     res["image"].sum().backward()
     assert pos.grad is not None and torch.isfinite(pos.grad).all() and pos.grad.abs().sum() > 0
+
+
+def _shadow_both_ways(scene, **kw):
+    """(binned, all-pairs) results of the shadow pass over the same primary frame."""
+    from surf_renderer_amd import renderer
+    buf = renderer.flatten_scene(scene, "cuda:0")
+    cam = renderer.camera_struct(scene["camera"], "torch")
+    out = []
+    for all_pairs in (False, True):
+        image, depth, nearest = renderer.render_buffers(buf, cam, shading="torch", **kw)
+        vis = renderer.shadow_pass(buf, cam, None, image, depth, nearest, kw.get("double_sided", False),
+                                   kw.get("use_quartic", False), all_pairs=all_pairs)
+        torch.cuda.synchronize()
+        out.append((image.clone(), vis.clone(), depth.clone()))
+    return out
+
+
+def _with_torch_inputs(scene):
+    n_l = np.asarray(scene["lights"]["pos"]).shape[0]
+    n_m = np.asarray(scene["materials"]["albedo"]).shape[0]
+    scene["lights"] = dict(scene["lights"], attenuation=np.array([[1, 0, 0]] * n_l, dtype=np.float32),
+                           ambient=np.array([0.02, 0.02, 0.02], dtype=np.float32))
+    scene["materials"] = dict(scene["materials"], coeffs=np.array([[0.8, 0.2, 6.0]] * n_m, dtype=np.float32))
+    return scene
+
+
+def test_binned_shadow_pass_equals_all_pairs_bit_for_bit():
+    """The light-space tile bins only select candidates; every candidate goes through the same fp64 test, so the
+    visibility bits and the re-shaded image equal the all-pairs pass exactly: fixtures' scenes, a disc cloud with the
+    lights outside (views), a light inside the cloud (no usable view -> that light takes all pairs), a light 0.05 in
+    front of an occluder (the near-ball rule), planes as receivers and occluders."""
+    from surf_renderer_amd import synthetic
+    cases = []
+    for name in ("s1a_mixed_shadow_64x48", "s1b_disk_cloud_shadow_64x64_ds"):
+        scene, _, kw = load_shadow_case(name)
+        cases.append((scene, kw))
+    cloud = _with_torch_inputs(synthetic.disk_cloud_scene(6000, 160, 128, radius=0.05, seed=3))
+    cases.append((cloud, {}))
+    inside = _with_torch_inputs(synthetic.disk_cloud_scene(3000, 96, 80, radius=0.06, seed=4))
+    lp = np.asarray(inside["lights"]["pos"], dtype=np.float32).copy()
+    lp[0] = [0.1, 0.05, 0.2, 1.0]                                   # inside the cloud
+    lp[1] = [0.0, 3.0, 0.0, 1.0]                                    # close above it
+    inside["lights"]["pos"] = lp
+    cases.append((inside, {"double_sided": True}))
+    mixed = _with_torch_inputs(synthetic.demo_scene(144, 112, with_planes=True))
+    mixed["camera"]["near"] = 0.5
+    # a light 0.05 in front of the first disc, on its normal: the disc is "behind the light" for rays arriving there
+    disk = mixed["objects"]["disk"]
+    n0 = np.asarray(disk["normal"], dtype=np.float64)[0, :3]
+    p0 = np.asarray(disk["pos"], dtype=np.float64)[0, :3]
+    lp = np.asarray(mixed["lights"]["pos"], dtype=np.float32).copy()
+    lp[0, :3] = (p0 + 0.05 * n0 / np.linalg.norm(n0)).astype(np.float32)
+    mixed["lights"]["pos"] = lp
+    cases.append((mixed, {}))
+    shadowed = 0
+    for scene, kw in cases:
+        (img_b, vis_b, depth), (img_a, vis_a, _) = _shadow_both_ways(scene, **kw)
+        assert torch.equal(vis_b, vis_a), f"{int((vis_b != vis_a).sum())} pixels differ in visibility"
+        assert torch.equal(img_b.view(torch.int32), img_a.view(torch.int32))
+        n_l = np.asarray(scene["lights"]["pos"]).shape[0]
+        hit = depth <= float(scene["camera"]["far"])
+        shadowed += int(((vis_a[hit] & ((1 << n_l) - 1)) != (1 << n_l) - 1).sum())
+    assert shadowed > 1000                                          # the cases do cast shadows
+
+
+def test_shadow_pass_accepts_the_small_workspace_as_all_pairs():
+    """A workspace sized by srh_workspace_bytes (no room for light views) still works: the all-pairs fallback."""
+    import ctypes as C
+    from surf_renderer_amd import _lib, renderer, synthetic
+    scene = _with_torch_inputs(synthetic.demo_scene(64, 48, with_planes=True))
+    buf = renderer.flatten_scene(scene, "cuda:0")
+    cam = renderer.camera_struct(scene["camera"], "torch")
+    lib = _lib.load()
+    small = lib.srh_workspace_bytes(C.byref(buf.objects), 64, 48)
+    big = lib.srh_shadow_workspace_bytes(C.byref(buf.objects), 64, 48, buf.lights.n_lights)
+    assert 0 < small < big
+    image, depth, nearest = renderer.render_buffers(buf, cam, shading="torch")
+    want = renderer.shadow_pass(buf, cam, None, image.clone(), depth, nearest)
+    vis = torch.empty_like(want)
+    params = _lib.SrhParams(row0=0, row1=48, mode=0, tonemap_gamma=0 if buf.gamma is None else 1,
+                            gamma=1.0 if buf.gamma is None else buf.gamma, shading=_lib.SHADING["torch"])
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda:0")
+    _lib.check(lib.srh_shadow_shade(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                    C.byref(params), ws.data_ptr(), ws.numel(), nearest.data_ptr(), depth.data_ptr(),
+                                    image.data_ptr(), vis.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(vis, want)

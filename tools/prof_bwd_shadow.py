@@ -113,10 +113,22 @@ def main():
             sc = synthetic.disk_cloud_scene(20_000, 512, 512)
             dt = timed(lambda: renderer.render(sc, device=DEV, validate=False, shading="torch", shadow=True), max(2, args.steps // 5), 1)
             out = {"case": case, "what": "20k discs 512x512, shading='torch', shadow=True", "ms_per_frame": 1e3 * dt}
-        elif case == "shadow_cfg5":
-            sc = synthetic.disk_cloud_scene(100_000, 2048, 2048)
-            dt = timed(lambda: renderer.render(sc, device=DEV, validate=False, shading="torch", shadow=True), max(2, args.steps // 5), 1)
-            out = {"case": case, "what": "100k discs 2048x2048 (config 5), shading='torch', shadow=True", "ms_per_frame": 1e3 * dt}
+        elif case in ("shadow_cfg5", "shadow_mesh_allpairs", "shadow_discs_allpairs"):
+            # the shadow pass alone over a resident frame: light-space bins (default) or the all-pairs loop
+            sc = {"shadow_cfg5": lambda: synthetic.disk_cloud_scene(100_000, 2048, 2048),
+                  "shadow_mesh_allpairs": lambda: synthetic.bunny_mesh_scene(512, 512),
+                  "shadow_discs_allpairs": lambda: synthetic.disk_cloud_scene(20_000, 512, 512)}[case]()
+            buf = renderer.flatten_scene(sc, DEV)
+            cam = renderer.camera_struct(sc["camera"], "torch")
+            image, depth, nearest = renderer.render_buffers(buf, cam, shading="torch")
+            out = {"case": case, "what": f"shadow pass alone, {buf.total} primitives, {image.shape[1]}x{image.shape[0]}, "
+                                         f"{buf.lights.n_lights} lights"}
+            for label, ap in (("binned_ms", False), ("all_pairs_ms", True)):
+                if ap and case == "shadow_cfg5":
+                    continue                       # ~1e12 fp64 pair tests: tens of seconds; priced by the smaller cases
+                dt = timed(lambda: renderer.shadow_pass(buf, cam, None, image, depth, nearest, all_pairs=ap),
+                           max(2, args.steps // 5), 1)
+                out[label] = 1e3 * dt
         else:
             raise SystemExit(f"unknown case {case}")
         print(json.dumps(out), flush=True)
