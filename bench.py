@@ -141,6 +141,123 @@ def cpu_baseline(scene, prims, width, height, npix):
                       f"{dt:.1f} s), oracle/np_oracle.py fp64, pixel tile 64; frames/s extrapolated"}
 
 
+def literal_root0_leg(args, buf, cam, device, rank, world, W, H):
+    """The metric's literal form, timed beside the default schedule so that one multi-GPU run answers both questions:
+    equal contiguous row slabs, every frame assembled on rank 0 by ONE gather per frame (dist.gather_rows), eager
+    launches, two frames in flight (the gather of one overlaps the render of the next).  Same warm-up rule, exactly
+    --steps timed frames, max over ranks; rank 0 checks its assembled frames against an eager full-frame render."""
+    from surf_renderer_amd import renderer
+    from surf_renderer_amd.dist import gather_rows, row_slab
+    from surf_renderer_amd.pipeline import slab_views
+    r0, r1 = row_slab(H, rank, world)
+    n_buf = 2
+    streams = [torch.cuda.Stream(device) for _ in range(n_buf)]
+    scratch = [buf.new_workspace(W, H) for _ in range(n_buf)]
+    frames = [torch.empty((H, 4 * W), dtype=torch.float32, device=device) if rank == 0 else None for _ in range(n_buf)]
+    slabs = [frames[b][r0:r1] if rank == 0 else torch.empty((r1 - r0, 4 * W), dtype=torch.float32, device=device)
+             for b in range(n_buf)]
+    pending = [None] * n_buf
+    count = [0]
+
+    def step():
+        b = count[0] % n_buf
+        count[0] += 1
+        with torch.cuda.stream(streams[b]):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+            image, depth = slab_views(slabs[b], W)
+            renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None), workspace=scratch[b])
+            pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
+
+    def fence():
+        for b in range(n_buf):
+            if pending[b] is not None:
+                with torch.cuda.stream(streams[b]):
+                    pending[b].wait()
+                pending[b] = None
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+    t_w = time.perf_counter()
+    for _ in range(max(args.warmup, 2)):
+        step()
+    fence()
+    spent = torch.tensor([time.perf_counter() - t_w], dtype=torch.float64, device=device)
+    dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+    per = max(float(spent.item()) / max(args.warmup, 2), 2e-5)
+    extra = int(min(max((args.warmup_ms * 1e-3 - float(spent.item())) / per, 0), 5000))
+    for _ in range(extra):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = torch.ones(1, device=device)
+    if rank == 0 and args.check:
+        ref = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
+        renderer.render_buffers(buf, cam, rows=(0, H), mode=args.mode, out=(*slab_views(ref, W), None))
+        torch.cuda.synchronize(device)
+        for b in range(min(n_buf, count[0])):
+            if not torch.equal(frames[b].view(torch.int32), ref.view(torch.int32)):
+                ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        raise SystemExit("[bench] literal gather-to-rank-0 leg: an assembled frame differs from the eager full-frame render")
+    el = float(el.item())
+    return {"value": args.steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / args.steps,
+            "collection": "gather to rank 0 per frame (one collective per frame)",
+            "rows_per_rank": "one contiguous slab, equal split", "launch": "eager", "frames_in_flight": n_buf,
+            "check": "rank 0's assembled frames equal an eager full-frame render bit for bit" if args.check else "off"}
+
+
+def measure_exchange(device, rank, world, W, H, reps=10):
+    """Measured rate of the two collections on this node's links, nothing else running: bytes that cross the links per
+    rank divided by the wall time of the collective alone (max over ranks).  all-to-all of one batch of `world` frames
+    (every rank sends and receives (P-1)/P of a frame); gather of one frame to rank 0 (rank 0 receives (P-1)/P of it)."""
+    from surf_renderer_amd.dist import exchange_frames, gather_rows, row_slab
+    h = H // world
+    out = {}
+    if H % world == 0:
+        send = torch.rand((world, h, 4 * W), dtype=torch.float32, device=device)
+        recv = torch.empty_like(send)
+        for _ in range(3):
+            exchange_frames(send, recv)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            exchange_frames(send, recv)
+        torch.cuda.synchronize(device)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = 1e3 * float(t.item()) / reps
+        sent = (world - 1) * h * 4 * W * 4.0
+        out["all_to_all_batch"] = {"ms": ms, "bytes_sent_per_rank": sent, "GB_s_per_rank_each_way": sent / (ms * 1e-3) / 1e9}
+    r0, r1 = row_slab(H, rank, world)
+    slab = torch.rand((r1 - r0, 4 * W), dtype=torch.float32, device=device)
+    full = torch.empty((H, 4 * W), dtype=torch.float32, device=device) if rank == 0 else None
+    for _ in range(3):
+        gather_rows(slab, full, H, dst=0)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gather_rows(slab, full, H, dst=0)
+    torch.cuda.synchronize(device)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = 1e3 * float(t.item()) / reps
+    recvd = (H - (row_slab(H, 0, world)[1] - row_slab(H, 0, world)[0])) * 4 * W * 4.0
+    out["gather_to_rank0_frame"] = {"ms": ms, "bytes_received_by_rank0": recvd,
+                                    "GB_s_into_rank0": recvd / (ms * 1e-3) / 1e9 if recvd else None}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -586,6 +703,16 @@ def main():
         if rank == 0:
             print(f"[bench] check ok: {check_note}", file=sys.stderr)
 
+    # Multi-GPU runs also report the metric's literal form (one gather per frame to rank 0, equal contiguous slabs) and
+    # the measured rate of both collections on this node's links, so the first hardware run replaces the link model of
+    # DESIGN.md section 5 with data.  Every rank takes part; outside the timed region above.
+    literal = link = None
+    if use_dist and not frames_par and not args.as_rank and os.environ.get("SRH_BENCH_BACKEND", "nccl") == "nccl":
+        already_literal = not batched
+        link = measure_exchange(device, rank, world, W, H)
+        if not already_literal:
+            literal = literal_root0_leg(args, buf, cam, device, rank, world, W, H)
+
     timed = [e for e in events if e is not None and (not args.as_rank or args.batch_call != "on")]
     kernel_ms = float(np.mean([e.elapsed_ms() for e in timed])) if timed else 0.0
     for e in events:
@@ -660,6 +787,10 @@ def main():
                                       "kernel time; peak = one wave-instruction per SIMD per 4 cycles, the measured issue "
                                       "cost of the kernel's instruction mix (profiles/r02_ubench_issue.txt)"} if pmc else None),
         }
+        if literal is not None:
+            out["literal_root0"] = literal
+        if link is not None:
+            out["links_measured"] = link
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)
         print(json.dumps(out), flush=True)

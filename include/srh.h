@@ -74,7 +74,7 @@ typedef struct SrhCamera {
   double far_clip;
   int32_t viewport[4];    /* x0, y0, x1, y1; W = x1 - x0, H = y1 - y0 */
   int32_t ortho;          /* 1: orthographic projection (torch/utils.py:461-468) -- SRH_SHADING_TORCH only (the numpy
-                             backend has none), forward only, all pairs in fp64; 0: perspective */
+                             backend has none); forward (all pairs in fp64), backward and srh_render_views; 0: perspective */
   int32_t up_is_unit;     /* 1: `up` is already the camera's y axis and is used as given.  The reference normalises a
                              list-typed `up` in float32 arithmetic (numpy/ops.py:99,109), which the host repeats with
                              the same numpy call before filling this; 0: y = up / |up| in float64 */

@@ -60,8 +60,10 @@ def build_scene():
     }
 
 
-def emit(name, **kw):
+def emit(name, camera=None, **kw):
     sc = build_scene()
+    if camera:
+        sc["camera"].update(camera)
     rng = np.random.RandomState(7)
     H, W = 36, 48
     g_img = f32(rng.uniform(-1, 1, size=(H, W, 3)))
@@ -71,7 +73,8 @@ def emit(name, **kw):
         return torch.tensor(np.asarray(a, dtype=np.float32), requires_grad=True)
 
     leaves = {}
-    tsc = {"camera": dict(sc["camera"], proj_type="perspective"), "tonemap": {"type": "gamma", "gamma": torch.tensor([0.8])}}
+    tsc = {"camera": dict(sc["camera"], proj_type=sc["camera"].get("proj_type", "perspective")),
+           "tonemap": {"type": "gamma", "gamma": torch.tensor([0.8])}}
     for k in ("eye", "at", "up"):
         tsc["camera"][k] = torch.tensor(sc["camera"][k], dtype=torch.float32)
     tsc["lights"] = {"pos": leaf(sc["lights"]["pos"]), "color_idx": torch.tensor(sc["lights"]["color_idx"]),
@@ -116,5 +119,11 @@ def emit(name, **kw):
 
 
 if __name__ == "__main__":
-    emit("g10_torch_autograd_phong")
-    emit("g10_torch_autograd_phong_ds_quartic", double_sided=True, use_quartic=True)
+    only = sys.argv[1:]
+    if not only or "g10" in only:
+        emit("g10_torch_autograd_phong")
+        emit("g10_torch_autograd_phong_ds_quartic", double_sided=True, use_quartic=True)
+    if not only or "g11" in only:
+        # orthographic projection (torch/utils.py:461-468): per-ray origins on the image plane, one direction; the
+        # reference's ortho branch works while the image fits one 4096-pixel tile (48 x 36 does)
+        emit("g11_torch_autograd_ortho", camera={"proj_type": "ortho", "fovy": float(np.deg2rad(100.0)), "focal_length": 4.0})

@@ -65,6 +65,7 @@ def render(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Optional
     npix = H * W
     eye = torch.tensor(eye_np[:3])
     d = torch.tensor(ray_np[:3].T.copy())                                   # (N,3)
+    orig = eye[None, :].expand(npix, 3)                                      # the numpy backend is perspective only
 
     t = torch.zeros(npix, dtype=torch.float64)
     nrm = torch.zeros((npix, 3), dtype=torch.float64)
@@ -80,7 +81,7 @@ def render(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Optional
             if kind == "sphere":
                 c = leaves["sphere.pos"][loc][:, :3]
                 r = leaves["sphere.radius"][loc]
-                oc = eye[None, :] - c
+                oc = orig[sel] - c
                 a = torch.sum(ds * ds, dim=-1)
                 b = 2 * torch.sum(oc * ds, dim=-1)
                 cc = torch.sum(oc * oc, dim=-1) - r * r
@@ -93,21 +94,21 @@ def render(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Optional
                 t1 = torch.where(ok & (t1 >= 0), t1, one)
                 t2 = torch.where(ok & (t2 >= 0), t2, one)
                 ts = torch.where(ok, torch.minimum(t1, t2), torch.zeros_like(t1))
-                p = eye[None, :] + ts[:, None] * ds
+                p = orig[sel] + ts[:, None] * ds
                 v = p - c
                 n = v / torch.sqrt(torch.sum(v * v, dim=-1, keepdim=True))
                 n = torch.where(ok[:, None], n, torch.zeros_like(n))
             else:
                 q = (leaves["triangle.face"][loc][:, 0, :3] if kind == "triangle" else leaves[f"{kind}.pos"][loc][:, :3])
                 n = _unit(leaves[f"{kind}.normal"][loc])[:, :3]
-                ts = torch.sum(n * (q - eye[None, :]), dim=-1) / torch.sum(n * ds, dim=-1)
+                ts = torch.sum(n * (q - orig[sel]), dim=-1) / torch.sum(n * ds, dim=-1)
             t = t.index_put((torch.as_tensor(sel),), ts)
             nrm = nrm.index_put((torch.as_tensor(sel),), n)
         start += count
 
     hit = torch.as_tensor(hit_np)
     # pixels that are not hit are background: depth inf, image tonemap(0)
-    p = eye[None, :] + t[:, None] * d
+    p = orig + t[:, None] * d
     lpos = leaves["lights.pos"][:, :3]
     lcol = leaves["colors"][np.asarray(scene["lights"]["color_idx"])]
     alb = leaves["materials.albedo"][mat]
@@ -168,14 +169,21 @@ def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Opti
     constant, as under the reference's autograd."""
     from . import np_oracle_tch
     cam = scene["camera"]
-    eye_np, ray_np, H, W = np_oracle_tch.generate_rays(cam)
+    if np_oracle_tch.is_ortho(cam):
+        # torch/utils.py:461-468: every ray has its own origin on the image plane and the one direction at - eye
+        eye_np, orig_np, dvec, H, W = np_oracle_tch.generate_rays_ortho(cam)
+        orig = torch.tensor(np.ascontiguousarray(orig_np))                  # (N,3)
+        d = torch.tensor(np.broadcast_to(dvec[None, :], orig_np.shape).copy())
+    else:
+        eye_np, ray_np, H, W = np_oracle_tch.generate_rays(cam)
+        d = torch.tensor(ray_np.T.copy())                                   # (N,3), unit
+        orig = torch.tensor(eye_np[:3])[None, :].expand(d.shape[0], 3)
     if ref is None:
         ref = np_oracle_tch.render(scene, double_sided=double_sided, use_quartic=use_quartic)
     nearest = np.asarray(ref["nearest"]).reshape(-1)
     hit_np = np.asarray(ref["depth"]).reshape(-1) <= cam["far"]
     npix = H * W
     eye = torch.tensor(eye_np[:3])
-    d = torch.tensor(ray_np.T.copy())                                       # (N,3), unit
 
     t = torch.zeros(npix, dtype=torch.float64)
     nrm = torch.zeros((npix, 3), dtype=torch.float64)
@@ -191,7 +199,7 @@ def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Opti
             if kind == "sphere":
                 c = leaves["sphere.pos"][loc][:, :3]
                 r = leaves["sphere.radius"][loc]
-                oc = eye[None, :] - c
+                oc = orig[sel] - c
                 a = torch.sum(ds * ds, dim=-1)
                 b = 2 * torch.sum(oc * ds, dim=-1)
                 cc = torch.sum(oc * oc, dim=-1) - r * r
@@ -199,18 +207,18 @@ def render_tch(scene: Dict[str, Any], leaves: Dict[str, torch.Tensor], ref: Opti
                 t1 = (-b - root) / (2 * a)
                 t2 = (-b + root) / (2 * a)
                 ts = torch.where(t1 >= 0, t1, t2)                             # the smaller non-negative root
-                p = eye[None, :] + ts[:, None] * ds
+                p = orig[sel] + ts[:, None] * ds
                 n = _unit3_eps(p - c)
             else:
                 q = (leaves["triangle.face"][loc][:, 0, :3] if kind == "triangle" else leaves[f"{kind}.pos"][loc][:, :3])
                 n = _unit3_eps(leaves[f"{kind}.normal"][loc][:, :3])
-                ts = torch.sum(n * (q - eye[None, :]), dim=-1) / torch.sum(n * ds, dim=-1)
+                ts = torch.sum(n * (q - orig[sel]), dim=-1) / torch.sum(n * ds, dim=-1)
             t = t.index_put((torch.as_tensor(sel),), ts)
             nrm = nrm.index_put((torch.as_tensor(sel),), n)
         start += count
 
     hit = torch.as_tensor(hit_np)
-    p = eye[None, :] + t[:, None] * d
+    p = orig + t[:, None] * d
     lpos = leaves["lights.pos"][:, :3]
     lcol = leaves["colors"][np.asarray(scene["lights"]["color_idx"])]
     att = leaves["lights.attenuation"]

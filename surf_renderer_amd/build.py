@@ -29,8 +29,8 @@ def hipcc() -> str:
     return exe
 
 
-def command(extra: List[str] = ()) -> List[str]:
-    return [hipcc(), *FLAGS, *extra, "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", LIB_PATH]
+def command(extra: List[str] = (), out: str = LIB_PATH) -> List[str]:
+    return [hipcc(), *FLAGS, *extra, "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", out]
 
 
 def stale() -> bool:
@@ -43,12 +43,18 @@ def stale() -> bool:
 def build_lib(force: bool = False, verbose: bool = False, extra: List[str] = ()) -> str:
     """Compile libsrh.so if missing or older than its sources; returns its path."""
     if force or stale():
-        cmd = command(list(extra))
+        # compile next to the target and rename into place: several ranks of one job may find the library missing at
+        # the same time, and none of them may ever dlopen a half-written file
+        tmp = f"{LIB_PATH}.tmp{os.getpid()}"
+        cmd = command(list(extra), out=tmp)
         if verbose:
-            print(" ".join(cmd), file=sys.stderr)
+            print(" ".join(cmd).replace(tmp, LIB_PATH), file=sys.stderr)
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+        os.replace(tmp, LIB_PATH)
         if verbose and proc.stderr:
             print(proc.stderr, file=sys.stderr)
     return LIB_PATH

@@ -866,6 +866,35 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     return fail(SRH_E_RANGE, "workspace holds %zu bytes, %d views need %zu", workspace_bytes, n_views,
                 head + (size_t)n_views * one);
   hipStream_t st = (hipStream_t)stream;
+  if (cameras[0].ortho) {
+    // Orthographic views (torch semantics): each view is the all-pairs fp64 frame of k_render_ortho -- its frame
+    // constants travel as kernel arguments, so this branch needs no staging, no ring and no lock.
+    if (params->shading != SRH_SHADING_TORCH)
+      return fail(SRH_E_CAMERA, "orthographic projection exists only under SRH_SHADING_TORCH");
+    char* wso = (char*)workspace;
+    const size_t rows = (size_t)(params->row1 - params->row0);
+    for (int v = 0; v < n_views; ++v) {
+      if (!cameras[v].ortho) return fail(SRH_E_CAMERA, "view %d is perspective, view 0 orthographic: one projection per call", v);
+      const int w = cameras[v].viewport[2] - cameras[v].viewport[0], h = cameras[v].viewport[3] - cameras[v].viewport[1];
+      if (w != W || h != H) return fail(SRH_E_RANGE, "view %d is %d x %d, view 0 is %d x %d", v, w, h, W, H);
+      FrameDev F;
+      WsLayout Lo;
+      SrhParams pv = *params;
+      if (params->view_row0) { pv.row0 = params->view_row0[v]; pv.row1 = pv.row0 + (params->row1 - params->row0); }
+      int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, wso + head + (size_t)v * one, one, &F, &Lo);
+      if (rc) return rc;
+      for (int s = 0; s < F.nseg; ++s) {
+        const SegDev& S = F.seg[s];
+        hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+      }
+      const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
+      hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, images + (size_t)v * rows * F.img_stride,
+                         depths + (size_t)v * rows * F.depth_stride,
+                         nearests ? nearests + (size_t)v * rows * F.near_stride : nullptr);
+    }
+    hipError_t eo = hipGetLastError();
+    return eo == hipSuccess ? SRH_OK : hip_fail(eo, "ortho views launch");
+  }
   int dev = 0;
   if (int rc = device_of(st, &dev)) return rc;
   if (dev < 0 || dev >= kMaxDevices) return fail(SRH_E_RANGE, "device %d: srh_render_views supports devices 0..%d", dev, kMaxDevices - 1);
@@ -908,7 +937,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
     }
     int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
-    if (F.ortho) return fail(SRH_E_CAMERA, "srh_render_views: perspective cameras only");
+    if (F.ortho) return fail(SRH_E_CAMERA, "view %d is orthographic, view 0 perspective: one projection per call", v);
     setup_binning(F, L, ws + head + (size_t)v * one);
   }
   const FrameDev* Fs = (const FrameDev*)ws;
@@ -1057,7 +1086,8 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   if (rc) return rc;
   if (!grad_image || !nearest || !depth || !grads)
     return fail(SRH_E_NULL, "grad_image / nearest / depth / grads is NULL");
-  if (F.ortho) return fail(SRH_E_CAMERA, "orthographic frames are forward only");
+  if (F.ortho && params->shading != SRH_SHADING_TORCH)
+    return fail(SRH_E_CAMERA, "orthographic projection exists only under SRH_SHADING_TORCH");
   GradsDev G;
   for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) {
     G.pos[s] = grads->pos[s]; G.normal[s] = grads->normal[s]; G.radius[s] = grads->radius[s]; G.face[s] = grads->face[s];

@@ -385,17 +385,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   // light visibility of the forward pass (shadow rays): a constant 0 / 1 factor on each light's colour x albedo term
   const uint64_t vis = (visibility && hit) ? visibility[row * (size_t)F.W + cc] : ~0ull;
 
-  double d[3] = {0, 0, -1};
-  pixel_ray(F, live ? c : 0, live ? r : F.row0, d);
+  // the pixel's ray: from the eye (perspective), or from its own origin eye + q0 on the image plane with the one
+  // direction -z of the camera basis (orthographic, torch/utils.py:461-468); org is what the reference calls ray_orig
+  double d[3] = {0, 0, -1}, q0[3] = {0, 0, 0};
+  if (F.ortho) {
+    const int pc = live ? c : 0, pr = live ? r : F.row0;
+    const double xs = (F.W > 1 && pc == F.W - 1) ? 1.0 : (pc * F.step_x + -1.0);
+    const double ys = (F.H > 1 && pr == F.H - 1) ? -1.0 : (pr * F.step_y + 1.0);
+    const double X = xs * F.half_w, Y = ys * F.half_h;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q0[i] = F.bx[i] * X + F.by[i] * Y; d[i] = -F.bz[i]; }
+  } else {
+    pixel_ray(F, live ? c : 0, live ? r : F.row0, d);
+  }
+  const double org[3] = {F.o[0] + q0[0], F.o[1] + q0[1], F.o[2] + q0[2]};
 
   // ---- forward quantities of this pixel ---------------------------------------------------------------------
   double t = 0.0, n[3] = {0, 0, 0}, p[3] = {0, 0, 0};
   double sph_inv = 0.0;                                    // sphere: 1 / sqrt(|p - c|^2 + 3e-10)
   const double* R = rec_base + (size_t)li * kRec64Stride[type];
   if (hit) {
-    t = hit_any64(type, R, F.o, d, true);
+    t = F.ortho ? hit_any64_from(type, R, F.o, q0, d) : hit_any64(type, R, F.o, d, true);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = F.o[k] + t * d[k];
+    for (int k = 0; k < 3; ++k) p[k] = org[k] + t * d[k];
     if (type == SRH_PRIM_SPHERE) {
       const float* cp = seg_ptr([](const SegDev& S) { return S.pos; }) + 4 * (size_t)li;
       double v[3];
@@ -593,9 +605,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
       gA[k] = -g_v;
     }
     const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
+    // oc = ray origin - centre: the record's eye-relative oc shifted by q0 (zero for perspective rays)
+    const double oc[3] = {R[0] + q0[0], R[1] + q0[1], R[2] + q0[2]};
+    const double cq = (R[3] + 2.0 * dot3(R, q0)) + dot3(q0, q0);
     const double a = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
-    const double b = 2.0 * dot3(R, d);
-    const double disc = b * b - 4.0 * a * R[3];
+    const double b = 2.0 * dot3(oc, d);
+    const double disc = b * b - 4.0 * a * cq;
     if (disc > 0.0) {
       const double root = sqrt(disc), inv2a = 1.0 / (2.0 * a);
       const double t1 = (-b - root) * inv2a;
@@ -606,10 +621,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
       const double g_cc = -4.0 * a * g_disc;
       g_r = -2.0 * (double)seg_ptr([](const SegDev& S) { return S.radius; })[li] * g_cc;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) gA[k] -= 2.0 * R[k] * g_cc + 2.0 * d[k] * g_b;   // oc = o - c
+      for (int k = 0; k < 3; ++k) gA[k] -= 2.0 * oc[k] * g_cc + 2.0 * d[k] * g_b;  // oc = origin - c
     }
   } else if (hit) {
-    // planar: t = k/den, k = n^.(q - o), den = n^.d
+    // planar: t = k/den, k = n^.(q - origin), den = n^.d
     const double g_t = ((g_p[0] * d[0] + g_p[1] * d[1]) + g_p[2] * d[2]) + g_dep;
     const double den = dot3(R, d);
     const double g_k = g_t / den, g_den = -g_t * t / den;
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       gA[k] = g_k * n[k];
-      g_nh[k] = g_n[k] + g_k * ((double)qp[k] - F.o[k]) + g_den * d[k];
+      g_nh[k] = g_n[k] + g_k * ((double)qp[k] - org[k]) + g_den * d[k];
     }
     // n^ = nin / sqrt(|nin|^2 + 3e-10) over xyz
     const float* np_ = seg_ptr([](const SegDev& S) { return S.normal; }) + 4 * (size_t)li;

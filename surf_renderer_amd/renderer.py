@@ -667,8 +667,8 @@ class ResidentScene:
         self.shading, self.mode = shading, mode
         self._camera = scene["camera"]
         self.cam = camera_struct(scene["camera"], shading)
-        if self.cam.ortho:
-            raise NotImplementedError("ResidentScene renders perspective cameras (orthographic frames are forward only)")
+        if self.cam.ortho and shading != "torch":
+            raise ValueError("orthographic projection exists only in the torch backend's semantics: shading='torch'")
         self.shade = (shading, bool(double_sided), bool(use_quartic), False)
         self.inputs = [self.buf.tensors[k] for k in _float_keys(self.buf, shading)]
         self.differentiable = any(t.requires_grad for t in self.inputs)
@@ -769,8 +769,6 @@ def render(scene: Dict[str, Any], **params) -> RenderResult:
     if cam.ortho:
         if shading != "torch":
             raise ValueError("orthographic projection exists only in the torch backend's semantics: shading='torch'")
-        if torch.is_grad_enabled() and any(t.requires_grad for t in inputs):
-            raise NotImplementedError("orthographic projection is forward only")
     if shading == "torch":
         # the torch backend's semantics
         shade = ("torch", bool(params.get("double_sided", False)), bool(params.get("use_quartic", False)), shadow)

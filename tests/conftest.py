@@ -12,9 +12,9 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 
 def golden_cases():
-    """Forward golden cases (g1..g8*); g9 / g10 hold gradients and have their own tests."""
+    """Forward golden cases (g1..g8*); g9 / g10 / g11 hold gradients and have their own tests."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "g*.npz")))
-    return [n for n in names if not n.startswith(("g9", "g10"))]
+    return [n for n in names if not n.startswith(("g9", "g10", "g11"))]
 
 
 def pytest_configure(config):

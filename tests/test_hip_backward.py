@@ -118,7 +118,7 @@ def _torch_shading_scene(name):
     """Scenes with the torch backend's extra inputs: the reference-pinned gradient fixture (all four primitive
     types, specular materials, ambient, three attenuation laws), and a disc cloud lit from both sides."""
     import json
-    if name.startswith("g10"):
+    if name.startswith(("g10", "g11")):
         npz = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
         from oracle.golden_io import unpack_scene
         return unpack_scene(npz), json.loads(str(npz["kwargs"]))
@@ -155,7 +155,8 @@ def _leaf_scene_tch(scene):
     return sc, leaves
 
 
-@pytest.mark.parametrize("name", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic", "cloud_ds"])
+@pytest.mark.parametrize("name", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic", "cloud_ds",
+                                  "g11_torch_autograd_ortho"])
 def test_torch_shading_backward_matches_gradient_oracle(name):
     """render(scene, shading='torch') under autograd: the analytic HIP backward of the Phong model against the fp64
     gradient oracle (itself pinned by the reference's torch autograd, tests/test_torch_oracle.py)."""

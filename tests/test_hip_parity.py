@@ -563,8 +563,10 @@ def test_render_views_refuses_what_it_cannot_do():
         render_views(scene, cams, device="cuda:0", shading="torch", shadow=True)
     with pytest.raises(TypeError, match="unexpected"):
         render_views(scene, cams, device="cuda:0", tile_size=4096)
-    with pytest.raises(Exception, match="perspective cameras only"):
-        render_views(scene, [dict(scene["camera"], proj_type="ortho")], device="cuda:0", shading="torch")
+    with pytest.raises(Exception, match="one projection per call"):           # perspective and orthographic views mixed
+        render_views(scene, [scene["camera"], dict(scene["camera"], proj_type="ortho")], device="cuda:0", shading="torch")
+    with pytest.raises(Exception, match="SRH_SHADING_TORCH"):                  # the numpy semantics have no ortho camera
+        render_views(scene, [dict(scene["camera"], proj_type="ortho")], device="cuda:0")
     assert render_views(scene, cams, device="cuda:0", shadow=False)["image"].shape == (1, 24, 32, 3)
 
 

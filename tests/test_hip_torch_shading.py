@@ -257,3 +257,20 @@ def test_shadow_pass_accepts_the_small_workspace_as_all_pairs():
                                     image.data_ptr(), vis.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(vis, want)
+
+
+def test_orthographic_views_in_one_call_equal_per_view_render():
+    from surf_renderer_amd import render, render_views
+    scene, _, kw = load_tch_case("t4_mixed_ortho_64x48")
+    cams = []
+    for k in range(4):
+        cam = dict(scene["camera"])
+        cam["eye"] = [float(0.4 * k - 0.5), 1.0 + 0.2 * k, 10.0, 1.0]
+        cams.append(cam)
+    batch = render_views(scene, cams, device="cuda:0", shading="torch", **kw)
+    torch.cuda.synchronize()
+    for i, cam in enumerate(cams):
+        single = render({**scene, "camera": cam}, device="cuda:0", shading="torch", **kw)
+        for k in ("image", "depth", "nearest"):
+            np.testing.assert_array_equal(batch[k][i].cpu().numpy(), single[k].cpu().numpy(), err_msg=f"view {i} {k}")
+    assert (batch["depth"] <= scene["camera"]["far"]).float().mean() > 0.3

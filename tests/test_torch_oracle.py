@@ -77,7 +77,7 @@ def test_gradients_are_consistent_with_finite_differences():
         np.testing.assert_allclose(grads[key][idx], fd, rtol=2e-5, atol=1e-7, err_msg=f"{key}{idx}")
 
 
-@pytest.mark.parametrize("case", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic"])
+@pytest.mark.parametrize("case", ["g10_torch_autograd_phong", "g10_torch_autograd_phong_ds_quartic", "g11_torch_autograd_ortho"])
 def test_phong_autograd_matches_reference_torch_backend(case):
     """Torch-backend semantics (attenuation, specular, ambient, per-light relu, double_sided, use_quartic): the fp64
     gradient oracle against what the reference's torch backend produced under autograd (float32).  The reference's
