@@ -622,6 +622,23 @@ def main():
             for b in range(n_buf):
                 enqueue((b,), streams[b], *views(slabs[b]), scratch[b], None)
         torch.cuda.synchronize(device)
+        if os.environ.get("SRH_BENCH_ADDRMAP"):
+            # diagnostic: every buffer a replay can touch, and the process's mappings, written out
+            # right after capture so that a faulting address reported by the driver can be attributed
+            amap = {"scratch": [(t.data_ptr(), t.numel()) for t in scratch],
+                    "scene": {k: (t.data_ptr(), t.numel() * t.element_size()) for k, t in buf.tensors.items()}}
+            if batched:
+                amap["send"] = [(t.data_ptr(), t.numel() * 4) for t in send]
+                amap["recv"] = [(t.data_ptr(), t.numel() * 4) for t in recv]
+            else:
+                amap["slabs"] = [(t.data_ptr(), t.numel() * 4) for t in slabs]
+            with open(os.environ["SRH_BENCH_ADDRMAP"], "w") as fh:
+                json.dump({k: ([(hex(a), n) for a, n in v] if isinstance(v, list) else
+                               {kk: (hex(a), n) for kk, (a, n) in v.items()}) for k, v in amap.items()}, fh, indent=1)
+                fh.write("\n--- /proc/self/maps ---\n")
+                fh.write(open("/proc/self/maps").read())
+                fh.flush()
+                os.fsync(fh.fileno())
     # Warm-up: the --warmup steps, then more untimed frames until --warmup-ms of wall time have passed since the first
     # one -- a handful of 0.1 ms frames does not bring the clocks up, and the timed region of a short run would then
     # be measured on a cold GPU.  Every rank runs the same number of extra frames (they contain collectives).
@@ -667,7 +684,7 @@ def main():
         ref = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
         renderer.render_buffers(buf, cam, rows=(0, H), mode=args.mode, out=(*views(ref), None))
         torch.cuda.synchronize(device)
-        rendered = args.warmup + args.steps
+        rendered = warm_steps + args.steps
         got = [recv[b] for b in range(n_bat)
                if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
         for t in got:                                  # the whole frame assembled on this rank, every rank's rows
@@ -691,7 +708,7 @@ def main():
             at += b_ - a
         torch.cuda.synchronize(device)
         if batched:                                    # my own slab inside the frames assembled on this rank
-            rendered = args.warmup + args.steps        # frames really rendered (a partial last batch has empty slots)
+            rendered = warm_steps + args.steps         # frames really rendered (a partial last batch has empty slots)
             got = [recv[b][rank] for b in range(n_bat)
                    if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
         else:

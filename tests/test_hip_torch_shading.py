@@ -60,18 +60,18 @@ def test_torch_shading_modes_identical_and_numpy_default_unchanged():
 
 
 def test_orthographic_projection_rules():
-    """proj_type 'ortho' exists in the torch backend only: the numpy shading model refuses it, gradients are not
-    offered, the stream-batched views refuse it; the frame itself is covered by the t4 / t5 fixtures above."""
-    from surf_renderer_amd import render, render_views
+    """proj_type 'ortho' exists in the torch backend only: the numpy shading model refuses it.  Under torch shading the
+    frame is covered by the t4 / t5 fixtures above, its gradients by golden g11 (tests/test_hip_backward.py), batched
+    views by test_orthographic_views_in_one_call_equal_per_view_render below."""
+    from surf_renderer_amd import render
     scene, _, kw = load_tch_case("t4_mixed_ortho_64x48")
     with pytest.raises(ValueError):
         render(scene, device="cuda:0")
     leaf = dict(scene, materials=dict(scene["materials"]))
     leaf["materials"]["albedo"] = torch.tensor(np.asarray(scene["materials"]["albedo"], dtype=np.float32), requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        render(leaf, device="cuda:0", shading="torch")
-    with pytest.raises(RuntimeError):
-        render_views(scene, [scene["camera"]], device="cuda:0", shading="torch")
+    res = render(leaf, device="cuda:0", shading="torch")
+    res["image"].sum().backward()
+    assert torch.isfinite(leaf["materials"]["albedo"].grad).all() and leaf["materials"]["albedo"].grad.abs().sum() > 0
     # a row slab of the orthographic frame equals the rows of the full frame
     full = _render(scene, **kw)
     part = _render(scene, rows=(10, 31), **kw)
