@@ -384,15 +384,12 @@ def main():
     pipe = None
 
     graphs = {}
-    # Graph replay is used on the single-process path only.  With a process group alive (RCCL kernels and device copies
-    # running beside the replays) the one-rank rehearsal `--force-dist --graph on` ended in a GPU memory fault on
-    # ROCm 7.2, while the same schedule with eager launches runs clean; multi-GPU runs therefore launch eagerly.
+    # Graph replay is the default on the single-process path only; --graph on asks for it with a process group too.
     graph_state = {"on": args.graph == "on" or (args.graph == "auto" and not use_dist), "captured": 0}
-    if graph_state["on"] and use_dist and not os.environ.get("SRH_BENCH_GRAPH_WITH_PG"):
-        # see DESIGN.md section 5: until that fault has a named cause this combination does not run
-        raise SystemExit("[bench] --graph on with a live process group is refused: this combination ended in a GPU "
-                         "memory fault in the round-1 rehearsal (DESIGN.md section 5).  SRH_BENCH_GRAPH_WITH_PG=1 "
-                         "overrides, for the diagnostic run only.")
+    # (Round 1's GPU memory fault of `--force-dist --graph on` is explained and fixed -- DESIGN.md section 5: the
+    # hipMemsetAsync node of a captured frame did not take effect in replays beside the process group, so bin counters
+    # accumulated and k_bin_fill wrote outside the workspace; the counters are now zeroed by a kernel and the fill index
+    # is bounded.  Multi-GPU runs still default to eager launches until graphs have run on real multi-rank hardware.)
 
     def enqueue(key, stream, image, depth, ws, ev, rows=None):
         """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,

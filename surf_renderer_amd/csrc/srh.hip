@@ -768,8 +768,12 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   const bool abl_skip_binning = !(stages & SRH_STAGE_BIN), abl_skip_render = !(stages & SRH_STAGE_RENDER);
   if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
-    hipError_t me = hipMemsetAsync(F.counters, 0, (kCounterPad + 2 * (size_t)F.nbins) * sizeof(uint32_t), st);
-    if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(counters)");
+    // Bin counters and fill cursors start every frame at zero.  A kernel, not hipMemsetAsync: captured into a hipGraph
+    // and replayed beside a live RCCL process group the memset NODE did not take effect, the counters grew from frame
+    // to frame and k_bin_fill's entry index walked off the workspace -- a kernel node has the
+    // same ordering as its neighbours by construction.
+    const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F.nbins;
+    hipLaunchKernelGGL(k_zero_counters, dim3((unsigned)((ncount + 1023) / 1024)), dim3(256), 0, st, F.counters, (uint32_t)ncount);
   }
 
   for (int s = 0; s < F.nseg && !abl_skip_binning; ++s) {

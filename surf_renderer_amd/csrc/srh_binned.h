@@ -163,11 +163,22 @@ __device__ __forceinline__ void bin_fill_body(const FrameDev& F) {
     if (!((mask >> k) & 1ull)) continue;
     const int bin = bin0 + (ty0 + k / nx) * F.tiles_x + (tx0 + k % nx);
     const uint32_t slot = atomicAdd(&cursor[bin], 1u);
-    F.entries[F.tile_off[bin] + slot] = (uint32_t)gidx;
+    // bounded by construction (slot < count[bin], offsets from the scan of the same counts); the check turns any
+    // inconsistency of the counters into a dropped entry instead of a write outside the workspace
+    const uint64_t at = (uint64_t)F.tile_off[bin] + slot;
+    if (at < (uint64_t)kMaxTilesPerPrim * (uint64_t)F.total) F.entries[at] = (uint32_t)gidx;
   }
 }
 
 __global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) { bin_fill_body(F); }
+
+// counters <- 0 (four words per thread)
+__global__ __launch_bounds__(256) void k_zero_counters(uint32_t* __restrict__ counters, uint32_t n) {
+  const uint32_t i = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (i + 3 < n) *reinterpret_cast<uint4*>(counters + i) = make_uint4(0u, 0u, 0u, 0u);
+  else
+    for (uint32_t k = i; k < n; ++k) counters[k] = 0u;
+}
 
 // ---- render: one wave per 16x16-pixel tile, four pixels (one row quad) per lane ---------------------------------
 //
