@@ -415,6 +415,30 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
         im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + (F.ambient ? (double)F.ambient[ch] : 0.0) * alb[ch];
     }
   } else {
+#ifdef SRH_SHADE_F32
+    // MEASUREMENT BUILD: the light loop in fp32 on two lights at a time (packed forms); the hit
+    // point and the light vectors are formed in fp64 and rounded, everything after that is fp32.  Not the product path:
+    // it needs the image tolerance loosened to ~2e-6 absolute (dark pixels, where the tonemap amplifies the sum's error).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 nx = {(float)n[0], (float)n[0]}, ny = {(float)n[1], (float)n[1]}, nz = {(float)n[2], (float)n[2]};
+    f2 acc[3] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+    for (int l = 0; l < F.nlights; l += 2) {
+      const double* L0 = F.lights64 + 6 * l;
+      const double* L1 = F.lights64 + 6 * min(l + 1, F.nlights - 1);
+      const float w1 = (l + 1 < F.nlights) ? 1.0f : 0.0f;
+      const f2 vx = {(float)(L0[0] - p[0]), (float)(L1[0] - p[0])}, vy = {(float)(L0[1] - p[1]), (float)(L1[1] - p[1])},
+               vz = {(float)(L0[2] - p[2]), (float)(L1[2] - p[2])};
+      f2 len2 = __builtin_elementwise_fma(vz, vz, __builtin_elementwise_fma(vy, vy, vx * vx));
+      len2 = len2 + f2{1.0e-37f, 1.0e-37f};
+      const f2 inv = {__builtin_amdgcn_rsqf(len2[0]), __builtin_amdgcn_rsqf(len2[1])};
+      const f2 nd = __builtin_elementwise_fma(nz, vz, __builtin_elementwise_fma(ny, vy, nx * vx)) * inv * f2{1.0f, w1};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) acc[ch] = __builtin_elementwise_fma(nd, f2{(float)L0[3 + ch], (float)L1[3 + ch]}, acc[ch]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) im[ch] = (double)(acc[ch][0] + acc[ch][1]);
+    if (false)
+#endif
     // sum_l (n . l^_l) colour_l, times the albedo once at the end (the reference multiplies inside the sum: equal to
     // ~1e-16, immaterial after the fp32 store); lights come as doubles from the per-frame copy
     for (int l = 0; l < F.nlights; ++l) {
