@@ -72,6 +72,7 @@ def parse():
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
                          "one stream for every frame's binning kernels, one for every frame's render kernel")
     ap.add_argument("--render-streams", type=int, default=2, help="--schedule stages: streams the render kernels alternate over")
+    ap.add_argument("--bin-priority", action="store_true", help="--schedule stages: the binning stream gets the higher priority")
     ap.add_argument("--flat-priority", action="store_true", help="--schedule stages: do not raise the render streams' priority")
     ap.add_argument("--gather", default="alltoall", choices=["alltoall", "root0"],
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
@@ -556,9 +557,14 @@ def main():
     elif not use_dist:
         # single process: surf_renderer_amd.pipeline.FramePipeline (the same object tests/test_hip_pipeline.py checks)
         from surf_renderer_amd.pipeline import FramePipeline
+        one_slab = None
+        if os.environ.get("SRH_BENCH_ONE_SLAB"):     # diagnostic: every frame in flight writes the same output slab
+            one_slab = [torch.empty((r1 - r0, 4 * W), dtype=torch.float32, device=device)] * \
+                (n_str * int(os.environ.get("SRH_BENCH_ROTATE", "1")))
         pipe = FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
-                             strict_graphs=args.graph == "on", schedule=args.schedule,
-                             render_streams=args.render_streams, prioritise_render=not args.flat_priority)
+                             slabs=one_slab, strict_graphs=args.graph == "on", schedule=args.schedule,
+                             render_streams=args.render_streams, prioritise_render=not args.flat_priority,
+                             prioritise_bin=args.bin_priority, rotate=int(os.environ.get("SRH_BENCH_ROTATE", "1")))
         graph_state["on"] = pipe.use_graphs
         graph_state["captured"] = pipe.captured
         n_buf, slabs = n_str, pipe.slabs

@@ -146,9 +146,9 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
   }
 }
 
-__global__ __launch_bounds__(256) void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
+__global__ __launch_bounds__(kBinBlock) void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
 
-__global__ __launch_bounds__(256) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
+__global__ __launch_bounds__(kBinBlock) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
   const FrameDev& F = Fs[blockIdx.y];
   prep_body(F, s, const_cast<double*>(F.seg[s].rec64), const_cast<float*>(F.seg[s].rec32));
 }
@@ -484,7 +484,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t lights64, tilerange, tilemask, counters, tile_off, large, entries;
+  size_t lights64, tilerange, tilemask, counters, tile_off, large, entries, entries_words;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -544,7 +544,9 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   L.large = off;
   off = align_up(off + total * sizeof(uint32_t));
   L.entries = off;
-  off = align_up(off + total * kMaxTilesPerPrim * sizeof(uint32_t));
+  // one-pass binning: every bin owns entries_words / nbins slots (at least kMinBinCap of them)
+  L.entries_words = std::max(total * kMaxTilesPerPrim, (size_t)SRH_MAX_SEGMENTS * ntiles * kMinBinCap);
+  off = align_up(off + L.entries_words * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -721,6 +723,7 @@ static void setup_binning(FrameDev& F, const WsLayout& L, void* workspace) {
   F.ntiles = F.tiles_x * F.tiles_y;
   F.ntiles_pad = (F.ntiles + 3) / 4 * 4;
   F.nbins = F.nseg * F.ntiles_pad;
+  F.bin_cap = (int32_t)std::min<size_t>(L.entries_words / (size_t)F.nbins, 1u << 20);
   char* ws = (char*)workspace;
   F.tilerange = (uint16_t*)(ws + L.tilerange);
   F.tilemask = (uint64_t*)(ws + L.tilemask);
@@ -778,13 +781,15 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
 
   for (int s = 0; s < F.nseg && !abl_skip_binning; ++s) {
     const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64,
+    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64,
                        (float*)S.rec32);
   }
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
-    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + 255) / 256)), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
+#if !SRH_ONEPASS
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
-    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + 255) / 256)), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
+#endif
   }
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
   if (abl_skip_render) {
@@ -795,10 +800,10 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                                                                                    : binned_waves_per_tile(F) == 4;
     if (F.shading) {
       if (split) hipLaunchKernelGGL((k_render_binned<true, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
-      else hipLaunchKernelGGL((k_render_binned<true, 1>), dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+      else hipLaunchKernelGGL((k_render_binned<true, 1>), dim3(groups * (4 / kWavesPerGroup1)), dim3(64 * kWavesPerGroup1), 0, st, F, image, depth, nearest);
     } else {
       if (split) hipLaunchKernelGGL((k_render_binned<false, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
-      else hipLaunchKernelGGL((k_render_binned<false, 1>), dim3(groups), dim3(256), 0, st, F, image, depth, nearest);
+      else hipLaunchKernelGGL((k_render_binned<false, 1>), dim3(groups * (4 / kWavesPerGroup1)), dim3(64 * kWavesPerGroup1), 0, st, F, image, depth, nearest);
     }
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
@@ -889,7 +894,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
       if (rc) return rc;
       for (int s = 0; s < F.nseg; ++s) {
         const SegDev& S = F.seg[s];
-        hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+        hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
       }
       const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
       hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, images + (size_t)v * rows * F.img_stride,
@@ -956,20 +961,22 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F0.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
   for (int s = 0; s < F0.nseg; ++s)
-    hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + 255) / 256, V), dim3(256), 0, st, Fs, s);
-  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + 255) / 256), V), dim3(256), 0, st, Fs);
+    hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, Fs, s);
+  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
+#if !SRH_ONEPASS
   hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, Fs);
-  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)F0.total * kFillLanes + 255) / 256), V), dim3(256), 0, st, Fs);
+  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)F0.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
+#endif
   const unsigned groups = binned_grid(F0);
   // all views share the GPU, so the batch as a whole decides the launch shape
   const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4)
                          ? params->waves_per_tile == 4 : (size_t)F0.ntiles * V < (size_t)SRH_SPLIT_TILES;
   if (F0.shading) {
     if (split) hipLaunchKernelGGL((k_render_binned_views<true, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups, V), dim3(256), 0, st, base, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups * (4 / kWavesPerGroup1), V), dim3(64 * kWavesPerGroup1), 0, st, base, images, depths, nearests);
   } else {
     if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups, V), dim3(256), 0, st, base, images, depths, nearests);
+    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups * (4 / kWavesPerGroup1), V), dim3(64 * kWavesPerGroup1), 0, st, base, images, depths, nearests);
   }
   // the slot is consumed only now: a call that failed validation above leaves the ring as it was
   const hipError_t er = hipEventRecord(ring.done[slot], st);
@@ -1026,7 +1033,7 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
   for (int s = 0; s < F.nseg; ++s) {
     const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
   const ShadowLayout SL = shadow_layout_for(objects, F.W, F.H, F.nlights);
@@ -1071,10 +1078,12 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   const size_t ncount = (size_t)kCounterPad + 2 * (size_t)T.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);
   for (int s = 0; s < T.nseg; ++s)
-    hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + 255) / 256, V), dim3(256), 0, st, frames, s);
-  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + 255) / 256), V), dim3(256), 0, st, frames);
+    hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, frames, s);
+  hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
+#if !SRH_ONEPASS
   hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, frames);
-  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)T.total * kFillLanes + 255) / 256), V), dim3(256), 0, st, frames);
+  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)T.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
+#endif
   hipLaunchKernelGGL(k_shadow_shade_binned, grid, block, 0, st, F, frames, image, depth, nearest, visibility);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SRH_OK : hip_fail(e, "shadow launch");
@@ -1107,7 +1116,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
   for (int s = 0; s < F.nseg; ++s) {
     const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + 255) / 256), dim3(256), 0, st, F, s, (double*)S.rec64,
+    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64,
                        (float*)S.rec32);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);

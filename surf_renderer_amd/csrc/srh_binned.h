@@ -61,6 +61,18 @@ __device__ __forceinline__ int rec32_stride(int type) {
        : type == SRH_PRIM_SPHERE ? kRec32Stride[2] : kRec32Stride[3];
 }
 
+// Workgroup size of the per-primitive kernels (prep, count, fill): ONE wave.  They run beside other frames' render
+// kernels, whose single-wave workgroups refill every slot the moment it is free; a four-wave workgroup would wait for
+// four free slots on one CU and starve.
+#ifndef SRH_BIN_BLOCK
+#define SRH_BIN_BLOCK 256
+#endif
+constexpr int kBinBlock = SRH_BIN_BLOCK;
+// Binning in ONE pass over the primitives (k_bin_count claims the slot and writes the entry; no scan, no fill), with
+// fixed-capacity bin lists; 0 = count, scan, fill with exact-size lists.
+#ifndef SRH_ONEPASS
+#define SRH_ONEPASS 1
+#endif
 #ifndef SRH_COUNT_LANES
 #define SRH_COUNT_LANES 2
 #endif
@@ -88,24 +100,65 @@ __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const RectTest T(type, rec32, F.near_clip > 0.0);
+#if SRH_ONEPASS
+  // one pass: the slot claimed in the bin's counter is the entry's place in the bin's fixed-capacity list
+  const uint32_t cap = (uint32_t)F.bin_cap;
+  uint32_t* slots = F.entries + (size_t)seg * F.ntiles_pad * cap;
+  int over = 0;
+#else
   uint64_t mask = 0;
+#endif
   for (int k = sub; k < n; k += kCountLanes) {
     const int tx = tx0 + k % nx, ty = ty0 + k / nx;
     const double pc0 = tx * kTile - F.bin_pad, pr0 = F.row0 + ty * kTile - F.bin_pad;
     const double pc1 = fmin(tx * kTile + kTile - 1, (double)(F.W - 1)) + F.bin_pad;
     const double pr1 = fmin(F.row0 + ty * kTile + kTile - 1, (double)(F.row1 - 1)) + F.bin_pad;
     if (T.reaches(pc0, pc1, pr0, pr1)) {
+#if SRH_ONEPASS
+      const uint32_t tile = (uint32_t)(ty * F.tiles_x + tx);
+      const uint32_t slot = atomicAdd(&count[tile], 1u);
+      if (slot < cap) slots[(size_t)tile * cap + slot] = (uint32_t)gidx;
+      else over = 1;
+#else
       mask |= 1ull << k;
       atomicAdd(&count[ty * F.tiles_x + tx], 1u);
+#endif
     }
   }
+#if SRH_ONEPASS
+  // a full bin: the primitive joins the batch's `large` list (tested by every tile) -- once, whatever the number of
+  // full bins; the bins that did take it keep it, a duplicate candidate changes no result
+#pragma unroll
+  for (int m = 1; m < kCountLanes; m <<= 1) over |= __shfl_xor(over, m);
+  if (sub == 0 && over) {
+    const uint32_t slot = atomicAdd(&F.counters[seg], 1u);
+    F.large[first + slot] = (uint32_t)gidx;
+  }
+#else
   uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
 #pragma unroll
   for (int m = 1; m < kCountLanes; m <<= 1) { lo |= __shfl_xor(lo, m); hi |= __shfl_xor(hi, m); }
   if (sub == 0) F.tilemask[gidx] = ((uint64_t)hi << 32) | lo;
+#endif
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(FrameDev F) { bin_count_body(F); }
+// the bin's list and its length (bin = seg * ntiles_pad + tile)
+__device__ __forceinline__ const uint32_t* bin_list(const FrameDev& F, int bin) {
+#if SRH_ONEPASS
+  return F.entries + (size_t)bin * (uint32_t)F.bin_cap;
+#else
+  return F.entries + F.tile_off[bin];
+#endif
+}
+__device__ __forceinline__ uint32_t bin_length(const FrameDev& F, int bin) {
+#if SRH_ONEPASS
+  return min(F.counters[kCounterPad + bin], (uint32_t)F.bin_cap);
+#else
+  return F.tile_off[bin + 1] - F.tile_off[bin];
+#endif
+}
+
+__global__ __launch_bounds__(kBinBlock) void k_bin_count(FrameDev F) { bin_count_body(F); }
 
 // ---- exclusive scan of the bin counts: one 1024-thread workgroup, 16-byte loads ---------------------------
 __device__ __forceinline__ void bin_scan_body(const FrameDev& F) {
@@ -170,7 +223,7 @@ __device__ __forceinline__ void bin_fill_body(const FrameDev& F) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_bin_fill(FrameDev F) { bin_fill_body(F); }
+__global__ __launch_bounds__(kBinBlock) void k_bin_fill(FrameDev F) { bin_fill_body(F); }
 
 // counters <- 0 (four words per thread)
 __global__ __launch_bounds__(256) void k_zero_counters(uint32_t* __restrict__ counters, uint32_t n) {
@@ -465,12 +518,65 @@ __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __r
   }
 }
 
+// The same stream fed by VECTOR loads: lane l fetches list entry l of a 64-entry chunk and that entry's record
+// (one coalesced list load, then kQuads 16-byte gathers per lane -- 64 records in flight at once, and the next chunk's
+// while this one is evaluated); entry e's record then reaches the scalar registers by v_readlane.  Costs one readlane
+// per record word instead of the scalar loads, but a record's latency is paid once per chunk, not once per entry.
+#ifndef SRH_SWEEP_VEC
+#define SRH_SWEEP_VEC 0
+#endif
+template <int TYPE, int WPT, class Op>
+__device__ __forceinline__ void stream_list_vec(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
+                                                uint32_t ord0, uint32_t part, int lane, Op&& op) {
+  if (n_all <= part) return;
+  constexpr int kQuads = kRec32Stride[TYPE] / 4;
+  const uint32_t n = (n_all - part + WPT - 1) / WPT;
+  const float4* base = reinterpret_cast<const float4*>(S.rec32);
+  const int first = S.first;
+  float4 cur[kQuads], nxt[kQuads];
+  auto fetch = [&](uint32_t c0, float4 (&dst)[kQuads]) {
+    const uint32_t k = min(c0 + (uint32_t)lane, n - 1);          // clamped: the spare lanes reload a valid record
+    const int g = (int)list[k * WPT + part];
+    const float4* r = base + (size_t)(g - first) * kQuads;
+#pragma unroll
+    for (int q = 0; q < kQuads; ++q) dst[q] = r[q];
+  };
+  fetch(0, cur);
+  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+    const bool more = c0 + 64 < n;
+    if (more) fetch(c0 + 64, nxt);
+    const uint32_t m = min(64u, n - c0);
+#pragma unroll 1
+    for (uint32_t e = 0; e < m; ++e) {
+      RejectRecord<TYPE> A;
+#pragma unroll
+      for (int q = 0; q < kQuads; ++q) {
+        A.v[4 * q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].x), (int)e));
+        A.v[4 * q + 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].y), (int)e));
+        A.v[4 * q + 2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].z), (int)e));
+        A.v[4 * q + 3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].w), (int)e));
+      }
+      op(A, 0, min(ord0 + (c0 + e) * WPT + part + 1, kOrdMask));
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < kQuads; ++q) cur[q] = nxt[q];
+    }
+  }
+}
+
 template <int TYPE, bool PRETEST, int WPT>
 __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
-                                           uint32_t ord0, QuadState& Q, uint32_t part) {
+                                           uint32_t ord0, QuadState& Q, uint32_t part, int lane) {
+#if SRH_SWEEP_VEC
+  stream_list_vec<TYPE, WPT>(S, list, n_all, ord0, part, lane, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
+    sweep_entry<TYPE, PRETEST>(R, field, Q);
+  });
+#else
   stream_list<TYPE, WPT>(S, list, n_all, ord0, part, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
     sweep_entry<TYPE, PRETEST>(R, field, Q);
   });
+#endif
 }
 
 // Re-sweep, lane-parallel: every lane whose pixel is still undecided (`open`) walks the tile's list again with the
@@ -548,20 +654,20 @@ struct TileLists {
   const FrameDev& F;
   int tile;
   __device__ __forceinline__ const uint32_t* list(int s, int pass) const {
-    return pass == 0 ? F.large + F.seg[s].first : F.entries + F.tile_off[s * F.ntiles_pad + tile];
+    return pass == 0 ? F.large + F.seg[s].first : bin_list(F, s * F.ntiles_pad + tile);
   }
   __device__ __forceinline__ uint32_t count(int s, int pass) const {
 #ifdef SRH_ABL_NOLOOP
     return 0;
 #else
     const int bin = s * F.ntiles_pad + tile;
-    return pass == 0 ? F.counters[s] : F.tile_off[bin + 1] - F.tile_off[bin];
+    return pass == 0 ? F.counters[s] : bin_length(F, bin);
 #endif
   }
 };
 
 template <bool PRETEST, int WPT>
-__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part) {
+__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part, int lane) {
   const TileLists L{F, tile};
   uint32_t ord0 = 0;
   for (int s = 0; s < F.nseg; ++s) {
@@ -571,10 +677,10 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
       switch (S.type) {
-        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
-        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
-        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
-        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST, WPT>(S, list, n, ord0, Q, part); break;
+        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
+        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
+        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
+        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
       }
       ord0 += n;
     }
@@ -696,6 +802,16 @@ __host__ inline unsigned binned_grid(const FrameDev& F) {
 #ifndef SRH_SPLIT_TILES
 #define SRH_SPLIT_TILES 3072
 #endif
+// Workgroup size of the one-wave-per-tile kernel.  Its waves never meet at a barrier, and tiles differ a lot in cost
+// (10th / 50th / 90th percentile of a wave's life at config 5: 3 / 29 / 50 us): with four waves per workgroup a
+// finished wave's slot stays empty until the workgroup's slowest wave is done and four slots are free together --
+// measured 3.0 resident waves per SIMD of the 4 the registers allow.  One wave per workgroup: a slot is refilled
+// as soon as its wave ends.
+#ifndef SRH_GROUP_WAVES
+#define SRH_GROUP_WAVES 4
+#endif
+constexpr int kWavesPerGroup1 = SRH_GROUP_WAVES;   // 1 or 4
+static_assert(kWavesPerGroup1 == 1 || kWavesPerGroup1 == 4, "SRH_GROUP_WAVES");
 // waves per tile of the render kernel (see k_render_binned): 4 below SRH_SPLIT_TILES tiles, else 1
 __host__ inline int binned_waves_per_tile(const FrameDev& F) { return F.ntiles < SRH_SPLIT_TILES ? 4 : 1; }
 
@@ -730,27 +846,32 @@ __device__ __forceinline__ void wave_lds_fence() {
 // fill 1024 SIMDs several times over.
 // F is restrict-qualified: in the many-views kernels it refers to device memory, and without the promise that no store
 // of this function touches it every store would force the frame constants to be read again
-template <bool TCH, int WPT>
-__device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ F, float* __restrict__ image,
-                                                   float* __restrict__ depth, int32_t* __restrict__ nearest) {
-  __shared__ Parked park[4][4][64];           // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
-  __shared__ int32_t front[4][4][64];         // global index of each pixel's front candidate (-1: none / saturated)
-  __shared__ uint8_t queue[4][256];           // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  int tx, ty;
-  {
+// Tile of a wave of the binned render grid (see "Workgroup -> tiles" above).  kWaves = waves of the workgroup.
+template <int WPT, int kWaves>
+__device__ __forceinline__ void binned_tile_of(const FrameDev& F, int wave, int& tx, int& ty) {
     // `group` = four tiles that are neighbours in x: one workgroup (WPT 1) or four consecutive ones on the same XCD
     const unsigned seq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-    const unsigned idx = WPT == 1 ? seq : seq >> 2;
-    const unsigned sub = WPT == 1 ? (unsigned)wave : (seq & 3u);
+    const unsigned idx = kWaves == 4 && WPT == 1 ? seq : seq >> 2;
+    const unsigned sub = kWaves == 4 && WPT == 1 ? (unsigned)wave : (seq & 3u);
     const unsigned q = idx / (kRegionW * kRegionH), within = idx % (kRegionW * kRegionH);
     const unsigned nrx = binned_regions_x(F);
     const unsigned region = q * 8u + ((xcd + 3u * ((q * 8u) / nrx)) & 7u);   // rotate the deal from one region row to the next
     const unsigned rx = region % nrx, ry = region / nrx;
     tx = (int)((rx * kRegionW + within % kRegionW) * 4u + sub);
     ty = (int)(ry * kRegionH + within / kRegionW);
-  }
+}
+
+template <bool TCH, int WPT>
+__device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ F, float* __restrict__ image,
+                                                   float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  constexpr int kWaves = WPT == 1 ? kWavesPerGroup1 : 4;   // waves of the workgroup
+  __shared__ Parked park[kWaves][4][64];      // [wave][pixel of the quad][lane]: conflict-free 16-byte writes
+  __shared__ int32_t front[kWaves][4][64];    // global index of each pixel's front candidate (-1: none / saturated)
+  __shared__ uint8_t queue[kWaves][256];      // [wave]: ids j * 64 + lane of the pixels with a candidate, row-major
+  const int wave = kWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  int tx, ty;
+  binned_tile_of<WPT, kWaves>(F, wave, tx, ty);
   // WPT 1: waves are independent, no block barrier below.  WPT 4: the whole workgroup shares the tile and leaves together.
   if (tx >= F.tiles_x || ty >= F.tiles_y) return;
   const int tile = ty * F.tiles_x + tx;
@@ -802,8 +923,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps
-    if (pretest) sweep_tile<true, WPT>(F, tile, Q, part);
-    else sweep_tile<false, WPT>(F, tile, Q, part);
+    if (pretest) sweep_tile<true, WPT>(F, tile, Q, part, lane);
+    else sweep_tile<false, WPT>(F, tile, Q, part, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Parked p;
@@ -989,7 +1110,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 }
 
 template <bool TCH, int WPT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(
+__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(
     FrameDev F, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
   render_binned_body<TCH, WPT>(F, image, depth, nearest);
 }
@@ -1001,9 +1122,9 @@ __global__ __launch_bounds__(256) void k_views_zero(const FrameDev* __restrict__
   const size_t n = (size_t)kCounterPad + 2 * (size_t)F.nbins;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) F.counters[i] = 0u;
 }
-__global__ __launch_bounds__(256) void k_bin_count_views(const FrameDev* __restrict__ Fs) { bin_count_body(Fs[blockIdx.y]); }
+__global__ __launch_bounds__(kBinBlock) void k_bin_count_views(const FrameDev* __restrict__ Fs) { bin_count_body(Fs[blockIdx.y]); }
 __global__ __launch_bounds__(1024) void k_bin_scan_views(const FrameDev* __restrict__ Fs) { bin_scan_body(Fs[blockIdx.y]); }
-__global__ __launch_bounds__(256) void k_bin_fill_views(const FrameDev* __restrict__ Fs) { bin_fill_body(Fs[blockIdx.y]); }
+__global__ __launch_bounds__(kBinBlock) void k_bin_fill_views(const FrameDev* __restrict__ Fs) { bin_fill_body(Fs[blockIdx.y]); }
 
 // The render kernel reads its view's frame constants from CONSTANT memory: loads from there are invariant, so hipcc
 // re-materialises them where they are used (as it does with a by-value kernel argument) instead of keeping 140 SGPRs
@@ -1014,7 +1135,7 @@ constexpr int kViewRing = 4;                       // batches in flight before t
 __constant__ FrameDev g_view_frames[kViewRing * kMaxViewsPerCall];
 
 template <bool TCH, int WPT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned_views(
+__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned_views(
     int base, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
   const FrameDev& F = g_view_frames[base + blockIdx.y];
   const size_t rows = (size_t)(F.row1 - F.row0), v = blockIdx.y;

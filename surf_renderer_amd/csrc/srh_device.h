@@ -18,6 +18,7 @@ namespace srh {
 constexpr int kRec64Stride[4] = {8, 4, 4, 24};   // doubles per primitive record, by SRH_PRIM_*
 constexpr int kTile = 16;                         // binning tile edge in pixels
 constexpr int kMaxTilesPerPrim = 64;              // primitives overlapping more tiles go to the `large` list
+constexpr int kMinBinCap = 16;                    // one-pass binning: smallest capacity of a bin list
 constexpr int kCounterPad = 64;                   // dwords in front of the per-tile counters
 
 // One scene['objects'] entry as the kernels see it.
@@ -53,7 +54,7 @@ struct FrameDev {
   float* pos_out;                    // optional (rows,W,3)
   // tile binning (BINNED mode): 16x16-pixel tiles over the rendered row slab
   int32_t tiles_x, tiles_y, ntiles, ntiles_pad;   // ntiles_pad = ntiles rounded up to a multiple of 4
-  int32_t nbins, pad1;                            // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile
+  int32_t nbins, bin_cap;                         // nbins = nseg * ntiles_pad; bin = seg * ntiles_pad + tile; entries per bin list
   // Row pre-cull of a slab render (binned mode, row0 > 0 or row1 < H): x - eye = a D0 + b Dc + g Dr puts a point on
   // image row g / a; slab_ma / slab_mg are the rows of [D0 Dc Dr]^-1 that give a and g, slab_na / slab_ng their
   // lengths.  slab_cull = 0 switches the test off (full frame, or a singular basis).

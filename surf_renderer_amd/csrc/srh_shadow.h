@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
         for (uint32_t i = 0; i < nbig; ++i) test(sg, (int)big[i]);
         if (inside) {
           const int bin = sg * LF.ntiles_pad + tile;
-          const uint32_t b0 = LF.tile_off[bin], b1 = LF.tile_off[bin + 1];
-          for (uint32_t i = b0; i < b1; ++i) test(sg, (int)LF.entries[i]);
+          const uint32_t* list = bin_list(LF, bin);
+          const uint32_t nlist = bin_length(LF, bin);
+          for (uint32_t i = 0; i < nlist; ++i) test(sg, (int)list[i]);
         }
       }
     }

@@ -40,7 +40,7 @@ class FramePipeline:
     def __init__(self, buf: renderer.SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                  n_inflight: int = 3, mode: str = "auto", graphs: bool = True, strict_graphs: bool = False,
                  slabs: Optional[List[torch.Tensor]] = None, schedule: str = "frames", render_streams: int = 2,
-                 prioritise_render: bool = True):
+                 prioritise_render: bool = True, prioritise_bin: bool = False, rotate: int = 1):
         """``schedule='frames'``: frame k runs whole on stream k % n_inflight.  ``schedule='stages'``: two streams, one
         for every frame's binning kernels and one for every frame's render kernel (``SrhParams.stages``): the
         latency-bound binning of frame k+1 runs beside the render kernel of frame k, render kernels never share the
@@ -57,16 +57,22 @@ class FramePipeline:
         self.width, self.height = renderer.frame_size(cam)
         self.rows = (0, self.height) if rows is None else (int(rows[0]), int(rows[1]))
         h = self.rows[1] - self.rows[0]
-        self.n = int(n_inflight)
+        # `rotate` x n_inflight (slab, scratch) pairs: frame k runs on stream k % n_inflight with pair k % n, so a
+        # pair always meets the same stream (its reuse is ordered) but comes round only every `rotate` turns
+        self.n_streams = int(n_inflight)
+        self.n = int(n_inflight) * max(1, int(rotate))
+        if rotate != 1 and schedule != "frames":
+            raise ValueError("rotate needs schedule='frames'")
         if schedule == "stages":
             # streams[0]: every frame's binning kernels; streams[1:]: the render kernels, frame k on 1 + k % R.  The
             # render streams get the higher priority: binning waves then only take what the render kernels leave.
             self.n_render = max(1, int(render_streams))
-            self.streams = [torch.cuda.Stream(self.device, priority=0)] + \
-                [torch.cuda.Stream(self.device, priority=-1 if prioritise_render else 0) for _ in range(self.n_render)]
+            pb, pr = (-1, 0) if prioritise_bin else (0, -1 if prioritise_render else 0)
+            self.streams = [torch.cuda.Stream(self.device, priority=pb)] + \
+                [torch.cuda.Stream(self.device, priority=pr) for _ in range(self.n_render)]
         else:
             self.n_render = 0
-            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n_streams)]
         self._bin_done = [torch.cuda.Event() for _ in range(self.n)] if schedule == "stages" else []
         self._render_done: List[Optional[torch.cuda.Event]] = [None] * self.n
         self.bin_graphs: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.n
@@ -100,14 +106,14 @@ class FramePipeline:
 
         try:
             for b in range(self.n):
-                with torch.cuda.stream(self.streams[0 if self.schedule == "stages" else b]):
+                with torch.cuda.stream(self.streams[0 if self.schedule == "stages" else b % self.n_streams]):
                     self._render(b)                              # warm: module load, allocator
                 torch.cuda.synchronize(self.device)
                 if self.schedule == "stages":
                     self.bin_graphs[b] = capture(self.streams[0], b, _lib.STAGE_BIN)
                     self.graphs[b] = capture(self.streams[1 + b % self.n_render], b, _lib.STAGE_RENDER)
                 else:
-                    self.graphs[b] = capture(self.streams[b], b, self._half())
+                    self.graphs[b] = capture(self.streams[b % self.n_streams], b, self._half())
         except Exception as exc:                                 # capture unsupported here: stay eager, say so
             if strict:
                 raise
@@ -147,7 +153,7 @@ class FramePipeline:
                 self._render_done[b].record(sr)
             return b
         g = self.graphs[b] if ev is None else None
-        with torch.cuda.stream(self.streams[b]):
+        with torch.cuda.stream(self.streams[b % self.n_streams]):
             if g is not None:
                 g.replay()
             else:
