@@ -142,7 +142,12 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
       }
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
     }
-    bin_primitive(F, s, S.type, Q, S.first + i, near_eye);
+    const TileBox box = bin_primitive(F, s, S.type, Q, S.first + i, near_eye);
+#if SRH_ONEPASS && SRH_FUSE_BIN
+    if (box.tx0 <= box.tx1) bin_place<1>(F, s, S.type, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1);
+#else
+    (void)box;
+#endif
   }
 }
 
@@ -785,7 +790,9 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                        (float*)S.rec32);
   }
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
+#if !(SRH_ONEPASS && SRH_FUSE_BIN)
     hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
+#endif
 #if !SRH_ONEPASS
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
     hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
@@ -962,7 +969,9 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
   for (int s = 0; s < F0.nseg; ++s)
     hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, Fs, s);
+#if !(SRH_ONEPASS && SRH_FUSE_BIN)
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
+#endif
 #if !SRH_ONEPASS
   hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, Fs);
   hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)F0.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
@@ -1079,7 +1088,9 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);
   for (int s = 0; s < T.nseg; ++s)
     hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, frames, s);
+#if !(SRH_ONEPASS && SRH_FUSE_BIN)
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
+#endif
 #if !SRH_ONEPASS
   hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, frames);
   hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)T.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);

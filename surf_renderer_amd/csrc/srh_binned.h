@@ -29,8 +29,10 @@ __device__ __forceinline__ int segment_of(const FrameDev& F, int gidx) {
 }
 
 // ---- tile range of one primitive (called from k_prep) ------------------------------------------------
-__device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const float* rec32, int gidx,
-                                     bool force_large = false) {
+struct TileBox { int tx0, ty0, tx1, ty1; };        // inclusive; tx0 > tx1: not binned (no pixel, or on the large list)
+
+__device__ inline TileBox bin_primitive(const FrameDev& F, int seg, int type, const float* rec32, int gidx,
+                                        bool force_large = false) {
   BBox b = bbox_full();
   if (force_large) { /* keep the full box */ }
   else if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) b = conic_bbox(rec32);
@@ -43,7 +45,7 @@ __device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const
     // inclusive pixel box, clamped to the rendered slab; empty -> the primitive touches no pixel at all
     const double c_lo = fmax(floor(b.c0), 0.0), c_hi = fmin(ceil(b.c1), (double)(F.W - 1));
     const double r_lo = fmax(floor(b.r0), (double)F.row0), r_hi = fmin(ceil(b.r1), (double)(F.row1 - 1));
-    if (!(c_lo <= c_hi) || !(r_lo <= r_hi)) return;
+    if (!(c_lo <= c_hi) || !(r_lo <= r_hi)) return TileBox{1, 0, 0, 0};
     tx0 = (int)c_lo / kTile; tx1 = (int)c_hi / kTile;
     ty0 = ((int)r_lo - F.row0) / kTile; ty1 = ((int)r_hi - F.row0) / kTile;
     is_large = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaxTilesPerPrim;
@@ -51,9 +53,10 @@ __device__ inline void bin_primitive(const FrameDev& F, int seg, int type, const
   if (is_large) {                                                 // the batch's region of `large` starts at seg.first
     const uint32_t slot = atomicAdd(&F.counters[seg], 1u);
     F.large[F.seg[seg].first + slot] = (uint32_t)gidx;
-    return;
+    return TileBox{1, 0, 0, 0};
   }
   tr[0] = (uint16_t)tx0; tr[1] = (uint16_t)ty0; tr[2] = (uint16_t)tx1; tr[3] = (uint16_t)ty1;
+  return TileBox{tx0, ty0, tx1, ty1};
 }
 
 __device__ __forceinline__ int rec32_stride(int type) {
@@ -73,6 +76,11 @@ constexpr int kBinBlock = SRH_BIN_BLOCK;
 #ifndef SRH_ONEPASS
 #define SRH_ONEPASS 1
 #endif
+// Place the primitive from k_prep itself (a thread per primitive walks its box right after it built the record): no
+// count kernel, and nobody reads the reject record back from another XCD.  Needs SRH_ONEPASS.
+#ifndef SRH_FUSE_BIN
+#define SRH_FUSE_BIN 1
+#endif
 #ifndef SRH_COUNT_LANES
 #define SRH_COUNT_LANES 2
 #endif
@@ -83,20 +91,12 @@ constexpr int kCountLanes = SRH_COUNT_LANES;
 // the eye; bit k of the primitive's tile mask = k-th tile of the box, row-major.  k_prep leaves this to a kernel of
 // its own because a thread per primitive walking up to 64 tiles in fp64 is a long serial chain on a launch that
 // has only a wave or two per SIMD.
-__device__ __forceinline__ void bin_count_body(const FrameDev& F) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int gidx = t / kCountLanes, sub = t % kCountLanes;
-  if (gidx >= F.total) return;                                  // whole lane groups leave together
-  const uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
-  const int tx0 = tr[0], ty0 = tr[1], tx1 = tr[2], ty1 = tr[3];
-  if (tx0 > tx1) return;
-  const int seg = segment_of(F, gidx);
-  int type = F.seg[0].type, first = F.seg[0].first;
-  const float* base = F.seg[0].rec32;
-#pragma unroll
-  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
-    if (seg == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec32; }
-  const float* rec32 = base + (size_t)(gidx - first) * rec32_stride(type);
+// The tiles of primitive gidx's box that its reject shape really reaches: kLanes lanes share the box (lane `sub` takes
+// tiles sub, sub + kLanes, ...).
+template <int kLanes>
+__device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, int first, const float* rec32, int gidx,
+                                          int sub, int tx0, int ty0, int tx1, int ty1) {
+  constexpr int kCountLanes = kLanes;
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const RectTest T(type, rec32, F.near_clip > 0.0);
@@ -140,6 +140,23 @@ __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
   for (int m = 1; m < kCountLanes; m <<= 1) { lo |= __shfl_xor(lo, m); hi |= __shfl_xor(hi, m); }
   if (sub == 0) F.tilemask[gidx] = ((uint64_t)hi << 32) | lo;
 #endif
+}
+
+__device__ __forceinline__ void bin_count_body(const FrameDev& F) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gidx = t / kCountLanes, sub = t % kCountLanes;
+  if (gidx >= F.total) return;                                  // whole lane groups leave together
+  const uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
+  const int tx0 = tr[0], ty0 = tr[1], tx1 = tr[2], ty1 = tr[3];
+  if (tx0 > tx1) return;
+  const int seg = segment_of(F, gidx);
+  int type = F.seg[0].type, first = F.seg[0].first;
+  const float* base = F.seg[0].rec32;
+#pragma unroll
+  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+    if (seg == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec32; }
+  const float* rec32 = base + (size_t)(gidx - first) * rec32_stride(type);
+  bin_place<kCountLanes>(F, seg, type, first, rec32, gidx, sub, tx0, ty0, tx1, ty1);
 }
 
 // the bin's list and its length (bin = seg * ntiles_pad + tile)
