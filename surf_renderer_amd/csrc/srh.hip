@@ -143,7 +143,7 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
     }
     const TileBox box = bin_primitive(F, s, S.type, Q, S.first + i, near_eye);
-#if SRH_ONEPASS && SRH_FUSE_BIN
+#if SRH_FUSE_BIN
     if (box.tx0 <= box.tx1) bin_place<1>(F, s, S.type, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1);
 #else
     (void)box;
@@ -489,7 +489,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t lights64, tilerange, tilemask, counters, tile_off, large, entries, entries_words;
+  size_t lights64, tilerange, counters, large, entries, entries_words;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -539,13 +539,9 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   const size_t ntiles = ((size_t)L.tiles_x * L.tiles_y_max + 3) / 4 * 4;
   L.tilerange = off;
   off = align_up(off + total * 4 * sizeof(uint16_t));
-  L.tilemask = off;
-  off = align_up(off + total * sizeof(uint64_t));
   L.counters = off;
-  L.counters_bytes = (kCounterPad + 2 * SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
+  L.counters_bytes = (kCounterPad + SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
   off = align_up(off + L.counters_bytes);
-  L.tile_off = off;
-  off = align_up(off + (SRH_MAX_SEGMENTS * ntiles + 4) * sizeof(uint32_t));
   L.large = off;
   off = align_up(off + total * sizeof(uint32_t));
   L.entries = off;
@@ -731,9 +727,7 @@ static void setup_binning(FrameDev& F, const WsLayout& L, void* workspace) {
   F.bin_cap = (int32_t)std::min<size_t>(L.entries_words / (size_t)F.nbins, 1u << 20);
   char* ws = (char*)workspace;
   F.tilerange = (uint16_t*)(ws + L.tilerange);
-  F.tilemask = (uint64_t*)(ws + L.tilemask);
   F.counters = (uint32_t*)(ws + L.counters);
-  F.tile_off = (uint32_t*)(ws + L.tile_off);
   F.large = (uint32_t*)(ws + L.large);
   F.entries = (uint32_t*)(ws + L.entries);
   F.slab_cull = 0;
@@ -776,11 +770,10 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   const bool abl_skip_binning = !(stages & SRH_STAGE_BIN), abl_skip_render = !(stages & SRH_STAGE_RENDER);
   if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
-    // Bin counters and fill cursors start every frame at zero.  A kernel, not hipMemsetAsync: captured into a hipGraph
-    // and replayed beside a live RCCL process group the memset NODE did not take effect, the counters grew from frame
-    // to frame and k_bin_fill's entry index walked off the workspace -- a kernel node has the
-    // same ordering as its neighbours by construction.
-    const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F.nbins;
+    // The bin counters start every frame at zero.  A kernel, not hipMemsetAsync: captured into a hipGraph and replayed
+    // beside a live RCCL process group the memset NODE did not take effect and the counters grew from frame to frame
+    //  -- a kernel node has the same ordering as its neighbours by construction.
+    const size_t ncount = (size_t)kCounterPad + (size_t)F.nbins;
     hipLaunchKernelGGL(k_zero_counters, dim3((unsigned)((ncount + 1023) / 1024)), dim3(256), 0, st, F.counters, (uint32_t)ncount);
   }
 
@@ -790,12 +783,8 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                        (float*)S.rec32);
   }
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
-#if !(SRH_ONEPASS && SRH_FUSE_BIN)
+#if !SRH_FUSE_BIN
     hipLaunchKernelGGL(k_bin_count, dim3((unsigned)(((size_t)F.total * kCountLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
-#endif
-#if !SRH_ONEPASS
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, F);
-    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((size_t)F.total * kFillLanes + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, st, F);
 #endif
   }
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
@@ -965,16 +954,12 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   if (e != hipSuccess) return hip_fail(e, "hipMemcpyToSymbolAsync(frames)");
   const FrameDev& F0 = stage[0];
   const unsigned V = (unsigned)n_views;
-  const size_t ncount = (size_t)kCounterPad + 2 * (size_t)F0.nbins;
+  const size_t ncount = (size_t)kCounterPad + (size_t)F0.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
   for (int s = 0; s < F0.nseg; ++s)
     hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, Fs, s);
-#if !(SRH_ONEPASS && SRH_FUSE_BIN)
+#if !SRH_FUSE_BIN
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
-#endif
-#if !SRH_ONEPASS
-  hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, Fs);
-  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)F0.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
 #endif
   const unsigned groups = binned_grid(F0);
   // all views share the GPU, so the batch as a whole decides the launch shape
@@ -1084,16 +1069,12 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   for (int s = 0; s < F.nseg; ++s)
     hipLaunchKernelGGL(k_scene_bounds, dim3((F.seg[s].count + 255) / 256), dim3(256), 0, st, F, s, bounds);
   hipLaunchKernelGGL(k_light_frames, dim3((V + 63) / 64), dim3(64), 0, st, T, F.lpos, F.nlights, bounds, frames, SL.slice.total);
-  const size_t ncount = (size_t)kCounterPad + 2 * (size_t)T.nbins;
+  const size_t ncount = (size_t)kCounterPad + (size_t)T.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);
   for (int s = 0; s < T.nseg; ++s)
     hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, frames, s);
-#if !(SRH_ONEPASS && SRH_FUSE_BIN)
+#if !SRH_FUSE_BIN
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
-#endif
-#if !SRH_ONEPASS
-  hipLaunchKernelGGL(k_bin_scan_views, dim3(1, V), dim3(1024), 0, st, frames);
-  hipLaunchKernelGGL(k_bin_fill_views, dim3((unsigned)(((size_t)T.total * kFillLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
 #endif
   hipLaunchKernelGGL(k_shadow_shade_binned, grid, block, 0, st, F, frames, image, depth, nearest, visibility);
   hipError_t e = hipGetLastError();

@@ -1,10 +1,11 @@
 // BINNED mode kernels (gfx950): screen-space tile binning + one WAVE per 16x16-pixel tile.
 //
-//   k_prep (srh.hip)   also writes each primitive's box of tiles, or appends it to its batch's `large` list
-//   k_bin_count        per primitive and tile of its box: does the reject shape reach the tile?  If so count the
-//                      primitive into that bin (atomicAdd on per-bin counters) and set the tile's bit in its mask
-//   k_bin_scan         exclusive prefix sum of the per-bin counts (one workgroup)
-//   k_bin_fill         second pass over the primitives: claim a slot per overlapped bin, write the index
+//   k_prep (srh.hip)   builds a primitive's records, finds its box of tiles (or appends it to its batch's `large`
+//                      list) and PLACES it: for every tile of the box the reject shape really reaches, an atomicAdd on
+//                      the bin's counter claims a slot of the bin's fixed-capacity list and the index goes there
+//                      (bin_place).  One pass over the primitives, no count / scan / fill.  A bin that is full sends
+//                      the primitive to the `large` list instead, which every tile tests.
+//   k_bin_count        the placement as a kernel of its own, two lanes per primitive (build switch SRH_FUSE_BIN=0)
 //   k_render_binned    per tile: sweep the tile's primitives, confirm the front one per pixel, shade, store
 //
 // A bin is (object batch, tile): every list the render kernel walks holds primitives of ONE type, so its
@@ -71,13 +72,8 @@ __device__ __forceinline__ int rec32_stride(int type) {
 #define SRH_BIN_BLOCK 256
 #endif
 constexpr int kBinBlock = SRH_BIN_BLOCK;
-// Binning in ONE pass over the primitives (k_bin_count claims the slot and writes the entry; no scan, no fill), with
-// fixed-capacity bin lists; 0 = count, scan, fill with exact-size lists.
-#ifndef SRH_ONEPASS
-#define SRH_ONEPASS 1
-#endif
 // Place the primitive from k_prep itself (a thread per primitive walks its box right after it built the record): no
-// count kernel, and nobody reads the reject record back from another XCD.  Needs SRH_ONEPASS.
+// count kernel, and nobody reads the reject record back from another XCD.
 #ifndef SRH_FUSE_BIN
 #define SRH_FUSE_BIN 1
 #endif
@@ -96,50 +92,52 @@ constexpr int kCountLanes = SRH_COUNT_LANES;
 template <int kLanes>
 __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, int first, const float* rec32, int gidx,
                                           int sub, int tx0, int ty0, int tx1, int ty1) {
-  constexpr int kCountLanes = kLanes;
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const RectTest T(type, rec32, F.near_clip > 0.0);
-#if SRH_ONEPASS
-  // one pass: the slot claimed in the bin's counter is the entry's place in the bin's fixed-capacity list
-  const uint32_t cap = (uint32_t)F.bin_cap;
-  uint32_t* slots = F.entries + (size_t)seg * F.ntiles_pad * cap;
-  int over = 0;
-#else
+  // pass 1, arithmetic only: bit k of `mask` = tile k of the box (row-major) is reached
   uint64_t mask = 0;
-#endif
-  for (int k = sub; k < n; k += kCountLanes) {
+  for (int k = sub; k < n; k += kLanes) {
     const int tx = tx0 + k % nx, ty = ty0 + k / nx;
     const double pc0 = tx * kTile - F.bin_pad, pr0 = F.row0 + ty * kTile - F.bin_pad;
     const double pc1 = fmin(tx * kTile + kTile - 1, (double)(F.W - 1)) + F.bin_pad;
     const double pr1 = fmin(F.row0 + ty * kTile + kTile - 1, (double)(F.row1 - 1)) + F.bin_pad;
-    if (T.reaches(pc0, pc1, pr0, pr1)) {
-#if SRH_ONEPASS
-      const uint32_t tile = (uint32_t)(ty * F.tiles_x + tx);
-      const uint32_t slot = atomicAdd(&count[tile], 1u);
-      if (slot < cap) slots[(size_t)tile * cap + slot] = (uint32_t)gidx;
-      else over = 1;
-#else
-      mask |= 1ull << k;
-      atomicAdd(&count[ty * F.tiles_x + tx], 1u);
-#endif
-    }
+    if (T.reaches(pc0, pc1, pr0, pr1)) mask |= 1ull << k;
   }
-#if SRH_ONEPASS
+  // pass 2: the slot claimed in a bin's counter is the entry's place in the bin's fixed-capacity list.  Four claims
+  // at a time, so that their round trips overlap instead of adding up (a thread owns ~6 bins on average).
+  const uint32_t cap = (uint32_t)F.bin_cap;
+  uint32_t* slots = F.entries + (size_t)seg * F.ntiles_pad * cap;
+  const uint32_t inv_nx = 65536u / (uint32_t)nx + 1u;            // k / nx == (k * inv_nx) >> 16 for k < 64, nx <= 64
+  int over = 0;
+  while (mask) {
+    uint32_t tile[4], slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tile[j] = 0xffffffffu;
+      if (mask) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t dy = (k * inv_nx) >> 16, dx = k - dy * (uint32_t)nx;
+        tile[j] = (uint32_t)(ty0 + (int)dy) * (uint32_t)F.tiles_x + (uint32_t)(tx0 + (int)dx);
+        slot[j] = atomicAdd(&count[tile[j]], 1u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tile[j] != 0xffffffffu) {
+        if (slot[j] < cap) slots[(size_t)tile[j] * cap + slot[j]] = (uint32_t)gidx;
+        else over = 1;
+      }
+  }
   // a full bin: the primitive joins the batch's `large` list (tested by every tile) -- once, whatever the number of
   // full bins; the bins that did take it keep it, a duplicate candidate changes no result
 #pragma unroll
-  for (int m = 1; m < kCountLanes; m <<= 1) over |= __shfl_xor(over, m);
+  for (int m = 1; m < kLanes; m <<= 1) over |= __shfl_xor(over, m);
   if (sub == 0 && over) {
-    const uint32_t slot = atomicAdd(&F.counters[seg], 1u);
-    F.large[first + slot] = (uint32_t)gidx;
+    const uint32_t at = atomicAdd(&F.counters[seg], 1u);
+    F.large[first + at] = (uint32_t)gidx;
   }
-#else
-  uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
-#pragma unroll
-  for (int m = 1; m < kCountLanes; m <<= 1) { lo |= __shfl_xor(lo, m); hi |= __shfl_xor(hi, m); }
-  if (sub == 0) F.tilemask[gidx] = ((uint64_t)hi << 32) | lo;
-#endif
 }
 
 __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
@@ -161,86 +159,13 @@ __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
 
 // the bin's list and its length (bin = seg * ntiles_pad + tile)
 __device__ __forceinline__ const uint32_t* bin_list(const FrameDev& F, int bin) {
-#if SRH_ONEPASS
   return F.entries + (size_t)bin * (uint32_t)F.bin_cap;
-#else
-  return F.entries + F.tile_off[bin];
-#endif
 }
 __device__ __forceinline__ uint32_t bin_length(const FrameDev& F, int bin) {
-#if SRH_ONEPASS
   return min(F.counters[kCounterPad + bin], (uint32_t)F.bin_cap);
-#else
-  return F.tile_off[bin + 1] - F.tile_off[bin];
-#endif
 }
 
 __global__ __launch_bounds__(kBinBlock) void k_bin_count(FrameDev F) { bin_count_body(F); }
-
-// ---- exclusive scan of the bin counts: one 1024-thread workgroup, 16-byte loads ---------------------------
-__device__ __forceinline__ void bin_scan_body(const FrameDev& F) {
-  __shared__ uint32_t part[1024];
-  const int tid = threadIdx.x;
-  const int n4 = F.nbins / 4;                              // nbins is a multiple of 4
-  const int per = (n4 + 1023) / 1024;
-  const int lo = min(tid * per, n4), hi = min(lo + per, n4);
-  const uint4* cnt = reinterpret_cast<const uint4*>(F.counters + kCounterPad);
-  uint32_t sum = 0;
-  for (int i = lo; i < hi; ++i) {
-    const uint4 v = cnt[i];
-    sum += (v.x + v.y) + (v.z + v.w);
-  }
-  part[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan of the partials
-    const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[tid] - sum;                          // exclusive prefix of this thread's chunk
-  uint4* out = reinterpret_cast<uint4*>(F.tile_off);
-  for (int i = lo; i < hi; ++i) {
-    const uint4 v = cnt[i];
-    uint4 o;
-    o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
-    run = o.w + v.w;
-    out[i] = o;
-  }
-  if (tid == 1023) F.tile_off[F.nbins] = part[1023];
-}
-
-__global__ __launch_bounds__(1024) void k_bin_scan(FrameDev F) { bin_scan_body(F); }
-
-#ifndef SRH_FILL_LANES
-#define SRH_FILL_LANES 16
-#endif
-constexpr int kFillLanes = SRH_FILL_LANES;
-
-// ---- fill: kFillLanes lanes per primitive, one (primitive, tile) pair per lane and step ---------------------
-__device__ __forceinline__ void bin_fill_body(const FrameDev& F) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int gidx = t / kFillLanes, sub = t % kFillLanes;
-  if (gidx >= F.total) return;
-  const uint16_t* tr = F.tilerange + 4 * (size_t)gidx;
-  const int tx0 = tr[0], ty0 = tr[1], tx1 = tr[2], ty1 = tr[3];
-  if (tx0 > tx1) return;
-  const int bin0 = segment_of(F, gidx) * F.ntiles_pad;
-  uint32_t* cursor = F.counters + kCounterPad + F.nbins;
-  const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-  const uint64_t mask = F.tilemask[gidx];
-  for (int k = sub; k < n; k += kFillLanes) {
-    if (!((mask >> k) & 1ull)) continue;
-    const int bin = bin0 + (ty0 + k / nx) * F.tiles_x + (tx0 + k % nx);
-    const uint32_t slot = atomicAdd(&cursor[bin], 1u);
-    // bounded by construction (slot < count[bin], offsets from the scan of the same counts); the check turns any
-    // inconsistency of the counters into a dropped entry instead of a write outside the workspace
-    const uint64_t at = (uint64_t)F.tile_off[bin] + slot;
-    if (at < (uint64_t)kMaxTilesPerPrim * (uint64_t)F.total) F.entries[at] = (uint32_t)gidx;
-  }
-}
-
-__global__ __launch_bounds__(kBinBlock) void k_bin_fill(FrameDev F) { bin_fill_body(F); }
 
 // counters <- 0 (four words per thread)
 __global__ __launch_bounds__(256) void k_zero_counters(uint32_t* __restrict__ counters, uint32_t n) {
@@ -863,6 +788,28 @@ __device__ __forceinline__ void wave_lds_fence() {
 // fill 1024 SIMDs several times over.
 // F is restrict-qualified: in the many-views kernels it refers to device memory, and without the promise that no store
 // of this function touches it every store would force the frame constants to be read again
+// image / depth stores: written once and never read again by the GPU -> nontemporal (config 5: -1 % job time;
+// sc1 write-through stores cost +6 %)
+#ifndef SRH_OUT_NT
+#define SRH_OUT_NT 1
+#endif
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void out_store(float* p, float v) {
+#if SRH_OUT_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void out_store4(float* p, float4 v) {
+#if SRH_OUT_NT
+  const vf4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<vf4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // Tile of a wave of the binned render grid (see "Workgroup -> tiles" above).  kWaves = waves of the workgroup.
 template <int WPT, int kWaves>
 __device__ __forceinline__ void binned_tile_of(const FrameDev& F, int wave, int& tx, int& ty) {
@@ -1007,15 +954,15 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
     const bool aligned = (((uintptr_t)px | (uintptr_t)dz | (uintptr_t)nr) & 15u) == 0;
     if (WPT == 1 && has == 0 && c0 + 3 < F.W && aligned) {
       const float4 v = make_float4(bg, bg, bg, bg);
-      reinterpret_cast<float4*>(px)[0] = v; reinterpret_cast<float4*>(px)[1] = v; reinterpret_cast<float4*>(px)[2] = v;
-      *reinterpret_cast<float4*>(dz) = make_float4(bgz, bgz, bgz, bgz);
+      out_store4(px, v); out_store4(px + 4, v); out_store4(px + 8, v);
+      out_store4(dz, make_float4(bgz, bgz, bgz, bgz));
       if (nr) *reinterpret_cast<int4*>(nr) = make_int4(0, 0, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if ((((mine & ~has) >> j) & 1u) && c0 + j < F.W) {
-          px[3 * j] = bg; px[3 * j + 1] = bg; px[3 * j + 2] = bg;
-          dz[j] = bgz;
+          out_store(px + 3 * j, bg); out_store(px + 3 * j + 1, bg); out_store(px + 3 * j + 2, bg);
+          out_store(dz + j, bgz);
           if (nr) nr[j] = 0;
         }
     }
@@ -1113,8 +1060,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 #endif
         const size_t row = (size_t)(r - F.row0);
         float* px = image + row * F.img_stride + 3 * (size_t)c;
-        px[0] = rgb[0]; px[1] = rgb[1]; px[2] = rgb[2];
-        depth[row * F.depth_stride + c] = background_depth(F, best);
+        out_store(px, rgb[0]); out_store(px + 1, rgb[1]); out_store(px + 2, rgb[2]);
+        out_store(depth + row * F.depth_stride + c, background_depth(F, best));
         if (want_aux) store_aux(F, row, c, aux);
 #ifdef SRH_DIAG_AGAIN   // diagnostic build: did this pixel take the slow path
         if (nearest) nearest[row * F.near_stride + c] = slow ? 1 : 0;
@@ -1136,12 +1083,10 @@ __global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute_
 // the views' outputs are stacked (V, rows, W, .) -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_views_zero(const FrameDev* __restrict__ Fs) {
   const FrameDev& F = Fs[blockIdx.y];
-  const size_t n = (size_t)kCounterPad + 2 * (size_t)F.nbins;
+  const size_t n = (size_t)kCounterPad + (size_t)F.nbins;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) F.counters[i] = 0u;
 }
 __global__ __launch_bounds__(kBinBlock) void k_bin_count_views(const FrameDev* __restrict__ Fs) { bin_count_body(Fs[blockIdx.y]); }
-__global__ __launch_bounds__(1024) void k_bin_scan_views(const FrameDev* __restrict__ Fs) { bin_scan_body(Fs[blockIdx.y]); }
-__global__ __launch_bounds__(kBinBlock) void k_bin_fill_views(const FrameDev* __restrict__ Fs) { bin_fill_body(Fs[blockIdx.y]); }
 
 // The render kernel reads its view's frame constants from CONSTANT memory: loads from there are invariant, so hipcc
 // re-materialises them where they are used (as it does with a by-value kernel argument) instead of keeping 140 SGPRs

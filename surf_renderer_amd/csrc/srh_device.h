@@ -61,11 +61,9 @@ struct FrameDev {
   double slab_ma[3], slab_mg[3], slab_na, slab_ng;
   int32_t slab_cull, pad3;
   uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
-  uint64_t* tilemask;                // (total) bit k = tile k of the range (row-major) really overlaps the shape
-  uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts | [64+nbins, 64+2 nbins) fill cursors
-  uint32_t* tile_off;                // (nbins+1) exclusive prefix of the bin counts
+  uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts
   uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)
-  uint32_t* entries;                 // (kMaxTilesPerPrim * total) binned global indices, grouped by bin
+  uint32_t* entries;                 // (nbins, bin_cap) binned global indices: bin b's list starts at b * bin_cap
   // Light views of the shadow pass (srh_shadow.h): bins are queried at CONTINUOUS positions, so a tile's rectangle grows
   // by bin_pad pixels on every side (0 for pixel-centre rendering), and primitives within near_ball of the eye go to
   // the `large` lists (every query tests them).  view_valid = 0: this light has no usable view (all-pairs fallback).

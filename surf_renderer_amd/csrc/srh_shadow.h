@@ -82,9 +82,7 @@ __global__ void k_light_frames(FrameDev T, const float* __restrict__ lpos, int n
   FrameDev F = T;
   const size_t by = (size_t)l * slice_bytes;
   F.tilerange = (uint16_t*)((char*)F.tilerange + by);
-  F.tilemask = (uint64_t*)((char*)F.tilemask + by);
   F.counters = (uint32_t*)((char*)F.counters + by);
-  F.tile_off = (uint32_t*)((char*)F.tile_off + by);
   F.large = (uint32_t*)((char*)F.large + by);
   F.entries = (uint32_t*)((char*)F.entries + by);
   F.lights64 = (const double*)((const char*)F.lights64 + by);

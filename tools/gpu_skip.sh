@@ -1,5 +1,4 @@
 #!/bin/bash
-export SRH_LIB=$PWD/build/abl/dclk.so SRH_DIAG_CLK=1
-mkdir -p gpurun_out/ring
-for fl in 3 1; do for d in none p32dummy,filldummy; do
-SRH_DIAG_SKIP=$d timeout -k 10 100 python tools/diag_time.py --inflight $fl 2>&1 | grep -E "diag|clock"; done; done
+run() { env $3 timeout -k 10 120 python bench.py --no-cpu-baseline --no-check $2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $2', '-> ms/step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4))"; }
+for fl in 1 2 3 4; do run base "--schedule render-only --inflight $fl" A=1; done
+for fl in 1 2 3; do run base "--schedule bin-only --inflight $fl" A=1; done
