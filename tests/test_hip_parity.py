@@ -211,6 +211,23 @@ def test_long_tile_lists_saturate_the_ordinal():
     _modes_identical(scene, modes=("exact", "binned"))
 
 
+def test_crowded_bins_overflow_to_the_frame_wide_list():
+    """One-pass binning gives every bin a fixed number of slots.  Crowd a few tiles of a frame with many tiles far
+    beyond that capacity (here 64 slots, ~1500 discs over a 3x3-tile patch): the discs that find their bin full go to
+    the frame-wide list that every tile tests, and the frame stays bit-identical to the all-pairs mode."""
+    from surf_renderer_amd import synthetic
+    for (w, h) in ((512, 512), (1024, 1024)):            # four waves per tile / one wave per tile
+        scene = synthetic.disk_cloud_scene(1500, w, h, radius=0.01, seed=23)
+        d = scene["objects"]["disk"]
+        rng = np.random.RandomState(5)
+        d["pos"][:, :2] = rng.uniform(-0.03, 0.03, size=(1500, 2)).astype(np.float32)      # a patch at the image centre
+        d["pos"][:1000, 2] = rng.uniform(-0.5, 0.5, size=1000).astype(np.float32)
+        # plus a sprinkling over the whole frame, so ordinary bins and crowded ones meet in one frame
+        d["pos"][1000:, :3] = rng.uniform(-1.0, 1.0, size=(500, 3)).astype(np.float32)
+        ref = _modes_identical(scene, modes=("exact", "binned"))
+        assert np.isfinite(ref["depth"]).any()
+
+
 def test_render_views_equals_per_view_render():
     """Batched multi-view rendering (several streams, shared scene) returns exactly what render() returns per view."""
     from surf_renderer_amd import render, render_views, synthetic
