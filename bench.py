@@ -78,8 +78,8 @@ def parse():
                     help="multi-GPU collection: batches of N frames, frame k assembled on rank k by one all-to-all "
                          "(default), or one gather per frame to rank 0")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay each frame's kernel sequence (memset, prep, count, scan, fill, render) as one "
-                         "hipGraph per output slot instead of six launches; auto = on for a single process (eager if "
+                    help="replay each frame's kernel sequence (clear, prep-and-bin, render) as one "
+                         "hipGraph per output slot instead of three launches; auto = on for a single process (eager if "
                          "capture fails), off when a process group is in use")
     ap.add_argument("--as-rank", default=None, metavar="R/P",
                     help="single-process rehearsal: render only the row slab rank R of a P-rank job would own (no "
@@ -380,7 +380,7 @@ def main():
         # whole batches are one library call; every 8th batch is rendered frame by frame with the events
         events = [_lib.EventPair() if (i // world) % 8 == 0 else None for i in range(args.steps)]
     else:
-        # never the first frames of the timed region: an eager frame there (seven launches instead of one replay) delays
+        # never the first frames of the timed region: an eager frame there (three launches instead of one replay) delays
         # the start of a pipeline that a short run has only a few frames to amortise
         events = [_lib.EventPair() if i % ev_every == ev_every // 2 else None for i in range(args.steps)]
     counter = [0]
@@ -391,8 +391,8 @@ def main():
     graph_state = {"on": args.graph == "on" or (args.graph == "auto" and not use_dist), "captured": 0}
     # (Round 1's GPU memory fault of `--force-dist --graph on` is explained and fixed -- DESIGN.md section 5: the
     # hipMemsetAsync node of a captured frame did not take effect in replays beside the process group, so bin counters
-    # accumulated and k_bin_fill wrote outside the workspace; the counters are now zeroed by a kernel and the fill index
-    # is bounded.  Multi-GPU runs still default to eager launches until graphs have run on real multi-rank hardware.)
+    # accumulated and k_bin_fill (since replaced by the one-pass binner, whose slot index is bounded by the bin's
+    # capacity) wrote outside the workspace; the counters are now zeroed by a kernel.  Multi-GPU runs still default to eager launches until graphs have run on real multi-rank hardware.)
 
     def enqueue(key, stream, image, depth, ws, ev, rows=None):
         """One frame's kernels on `stream`: replay of the hipGraph captured for this (output slot, scratch) pair,
@@ -480,7 +480,7 @@ def main():
         send, recv = batcher.send, batcher.recv
 
         # One library call per batch: the P frames of a batch are the "views" of srh_render_views, rendered straight
-        # into the send buffer -- 7 launches per batch instead of 7 per frame, which is what a rank's small slab needs
+        # into the send buffer -- one set of launches per batch instead of one per frame, which is what a rank's small slab needs
         # (its kernels are short; per-frame launches leave the GPU idle between them).  Every `ev_every`-th batch is
         # still rendered frame by frame with the timing events around the render kernel.
         batch_call = args.batch_call != "off"

@@ -151,7 +151,12 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
   }
 }
 
-__global__ __launch_bounds__(kBinBlock) void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
+#ifndef SRH_PREP_WAVES
+#define SRH_PREP_ATTR
+#else
+#define SRH_PREP_ATTR __attribute__((amdgpu_waves_per_eu(SRH_PREP_WAVES)))
+#endif
+__global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
 
 __global__ __launch_bounds__(kBinBlock) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
   const FrameDev& F = Fs[blockIdx.y];

@@ -1,9 +1,9 @@
 """Frames in flight: the single-process frame pipeline that bench.py times and tests/test_hip_pipeline.py checks.
 
-A frame is seven short kernels (clear, prep, count, scan, fill, render); the binning kernels are latency-bound, so
+A frame is three kernels (clear, prep-and-bin, render); the binning is latency-bound, so
 `n_inflight` frames run on their own HIP streams with their own scratch and output slab, and the binning of one frame
 overlaps the render kernel of another.  Each (output slab, scratch) pair's kernel sequence can be captured once as a
-hipGraph and replayed (one host call per frame instead of seven launches).  Everything a replay touches is owned by
+hipGraph and replayed (one host call per frame instead of three launches).  Everything a replay touches is owned by
 this object and stays alive with it: the scene buffers, the scratch, the slabs and the graphs.
 
 Reference call it stands for: a loop of ``render(scene)`` calls over one resident scene

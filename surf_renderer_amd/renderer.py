@@ -574,7 +574,7 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     """Many cameras, one scene: the batch axis of the reference's real callers (one ``render()`` per view in a
     Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once.  In the
     default binned mode the views go to the library ``batch`` at a time (``srh_render_views``): every kernel of the
-    frame pipeline is launched once per batch with the view as a grid dimension, so small views neither pay six
+    frame pipeline is launched once per batch with the view as a grid dimension, so small views neither pay three
     launches each nor leave the GPU idle.  Other modes, or ``batch=0``, issue one call per view round-robin over
     ``streams`` HIP streams.  All
     cameras must share one viewport size.  Returns stacked tensors ``image`` (B,H,W,3), ``depth`` (B,H,W) and

@@ -23,8 +23,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH",
           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES",
           "TCC_HIT_sum TCC_MISS_sum"]
-NAMES = {"k_render_binned": "k_render_binned", "k_bin_count": "k_bin_count", "k_bin_fill": "k_bin_fill",
-         "k_bin_scan": "k_bin_scan", "k_prep": "k_prep", "fillBufferAligned": "memset"}
+NAMES = {"k_render_binned": "k_render_binned", "k_bin_count": "k_bin_count", "k_prep": "k_prep",
+         "k_zero_counters": "k_zero_counters"}
 
 
 def main():
