@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
 // multiply) and the nearest-hit selection.  torch.pow: 0^0 = 1, d/d exponent = 0 at base 0, d/d base = 0 at exponent 0.
 // Misses and the far + 1 background carry no gradient.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
+#ifndef SRH_BWD_TCH_WAVES
+#define SRH_BWD_TCH_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_BWD_TCH_WAVES))) void k_render_bwd_tch(FrameDev F, GradsDev G, const float* __restrict__ grad_image,
                                                          const float* __restrict__ grad_depth,
                                                          const int32_t* __restrict__ nearest,
                                                          const float* __restrict__ depth,
