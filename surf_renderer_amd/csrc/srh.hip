@@ -47,7 +47,7 @@ size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 // ------------------------------------------------------------------------------------------------
 // k_prep: per-frame primitive records
 // ------------------------------------------------------------------------------------------------
-__device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R);
+__device__ __forceinline__ void prep_record64(const SegDev& S, int type, int i, const double o[3], bool tch, double* R);
 
 // Can no pixel of rows [row0, row1) see anything of the ball (centre x relative to the eye, radius rho)?  The ball's
 // points have a in a0 +- rho |m_a| and g in g0 +- rho |m_g| (Cauchy-Schwarz) and lie on image row g / a; rays exist
@@ -89,6 +89,10 @@ __device__ inline bool primitive_misses_slab(const FrameDev& F, const SegDev& S,
   return ball_misses_slab(F, x, rho);
 }
 
+// TYPE = the batch's primitive type (the host launches the matching instantiation): the fp64 record and the reject
+// record are built in REGISTERS, stored once, and the tile box and the bin placement work from the register copies --
+// a thread never waits for its own stores to come back (measured: the kernel was 76 % s_waitcnt).
+template <int TYPE>
 __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec64, float* rec32) {
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,17 +113,24 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
     tr[0] = 1; tr[1] = 0; tr[2] = 0; tr[3] = 0;                   // not binned
     return;
   }
-  double* R = rec64 + (size_t)i * kRec64Stride[S.type];
-  prep_record64(S, i, F.o, F.shading != 0, R);
-  // screen-space reject record of the FAST / binned modes, from the fp64 record just written
-  float* Q = rec32 + (size_t)i * kRec32Stride[S.type];
+  constexpr int N64 = kRec64Stride[TYPE], N32 = kRec32Stride[TYPE];
+  double R[N64];
+  prep_record64(S, TYPE, i, F.o, F.shading != 0, R);
+  // screen-space reject record of the FAST / binned modes, from the fp64 record
+  float Q[N32];
   const PixelBasis B = pixel_basis(F);
   const bool near_pos = F.near_clip > 0.0;
-  switch (S.type) {
-    case SRH_PRIM_DISK: disk_reject_record(R, B, F.W, F.H, Q); break;
-    case SRH_PRIM_SPHERE: sphere_reject_record(R, B, F.W, F.H, near_pos, F.shading != 0, Q); break;
-    case SRH_PRIM_TRIANGLE: triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q); break;
-    default: plane_reject_record(R, B, F.W, F.H, Q); break;
+  if (TYPE == SRH_PRIM_DISK) disk_reject_record(R, B, F.W, F.H, Q);
+  else if (TYPE == SRH_PRIM_SPHERE) sphere_reject_record(R, B, F.W, F.H, near_pos, F.shading != 0, Q);
+  else if (TYPE == SRH_PRIM_TRIANGLE) triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q);
+  else plane_reject_record(R, B, F.W, F.H, Q);
+  {
+    double2* r2 = reinterpret_cast<double2*>(rec64 + (size_t)i * N64);      // records are 16-byte aligned (strides 4, 8, 24)
+#pragma unroll
+    for (int k = 0; k < N64 / 2; ++k) r2[k] = make_double2(R[2 * k], R[2 * k + 1]);
+    float4* q4 = reinterpret_cast<float4*>(rec32 + (size_t)i * N32);
+#pragma unroll
+    for (int k = 0; k < N32 / 4; ++k) q4[k] = make_float4(Q[4 * k], Q[4 * k + 1], Q[4 * k + 2], Q[4 * k + 3]);
   }
   if (F.tilerange) {
     // light views: a primitive that comes within near_ball of the eye can block a shadow ray from BEHIND the light
@@ -128,23 +139,24 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
     bool near_eye = false;
     if (F.near_ball > 0.0) {
       double dmin = 0.0;
-      if (S.type == SRH_PRIM_DISK) dmin = sqrt(dot3(R + 4, R + 4)) - sqrt(fabs(R[7]));
-      else if (S.type == SRH_PRIM_SPHERE) dmin = sqrt(dot3(R, R)) - sqrt(fabs(dot3(R, R) - R[3]));
-      else if (S.type == SRH_PRIM_TRIANGLE) {
+      if (TYPE == SRH_PRIM_DISK) dmin = sqrt(dot3(R + 4, R + 4)) - sqrt(fabs(R[7]));
+      else if (TYPE == SRH_PRIM_SPHERE) dmin = sqrt(dot3(R, R)) - sqrt(fabs(dot3(R, R) - R[3]));
+      else if (TYPE == SRH_PRIM_TRIANGLE) {
         double far2 = 0.0, near2 = 1.0e300;
+#pragma unroll
         for (int v = 0; v < 3; ++v) {
           const double w[3] = {R[4 + 3 * v] - F.o[0], R[5 + 3 * v] - F.o[1], R[6 + 3 * v] - F.o[2]};
           near2 = fmin(near2, dot3(w, w));
-          const double* e = R + 13 + 3 * v;
+          const double e[3] = {R[13 + 3 * v], R[14 + 3 * v], R[15 + 3 * v]};
           far2 = fmax(far2, dot3(e, e));
         }
         dmin = sqrt(near2) - sqrt(far2);                        // every point is within one edge length of a vertex
       }
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
     }
-    const TileBox box = bin_primitive(F, s, S.type, Q, S.first + i, near_eye);
+    const TileBox box = bin_primitive(F, s, TYPE, Q, S.first + i, near_eye);
 #if SRH_FUSE_BIN
-    if (box.tx0 <= box.tx1) bin_place<1>(F, s, S.type, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1);
+    if (box.tx0 <= box.tx1) bin_place<1>(F, s, TYPE, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1);
 #else
     (void)box;
 #endif
@@ -156,16 +168,43 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
 #else
 #define SRH_PREP_ATTR __attribute__((amdgpu_waves_per_eu(SRH_PREP_WAVES)))
 #endif
-__global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep(FrameDev F, int s, double* rec64, float* rec32) { prep_body(F, s, rec64, rec32); }
-
-__global__ __launch_bounds__(kBinBlock) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
-  const FrameDev& F = Fs[blockIdx.y];
-  prep_body(F, s, const_cast<double*>(F.seg[s].rec64), const_cast<float*>(F.seg[s].rec32));
+template <int TYPE>
+__global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
+  prep_body<TYPE>(F, s, rec64, rec32);
 }
 
-__device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tch, double* R) {
+template <int TYPE>
+__global__ __launch_bounds__(kBinBlock) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
+  const FrameDev& F = Fs[blockIdx.y];
+  prep_body<TYPE>(F, s, const_cast<double*>(F.seg[s].rec64), const_cast<float*>(F.seg[s].rec32));
+}
+
+// host side: the instantiation for the batch's type
+static void launch_prep(const FrameDev& F, int s, hipStream_t st) {
+  const SegDev& S = F.seg[s];
+  const dim3 grid((S.count + kBinBlock - 1) / kBinBlock), block(kBinBlock);
+  double* r64 = (double*)S.rec64;
+  float* r32 = (float*)S.rec32;
+  switch (S.type) {
+    case SRH_PRIM_DISK: hipLaunchKernelGGL(k_prep<SRH_PRIM_DISK>, grid, block, 0, st, F, s, r64, r32); break;
+    case SRH_PRIM_PLANE: hipLaunchKernelGGL(k_prep<SRH_PRIM_PLANE>, grid, block, 0, st, F, s, r64, r32); break;
+    case SRH_PRIM_SPHERE: hipLaunchKernelGGL(k_prep<SRH_PRIM_SPHERE>, grid, block, 0, st, F, s, r64, r32); break;
+    default: hipLaunchKernelGGL(k_prep<SRH_PRIM_TRIANGLE>, grid, block, 0, st, F, s, r64, r32); break;
+  }
+}
+static void launch_prep_views(const FrameDev& F0, const FrameDev* Fs, int s, int V, hipStream_t st) {
+  const dim3 grid((F0.seg[s].count + kBinBlock - 1) / kBinBlock, V), block(kBinBlock);
+  switch (F0.seg[s].type) {
+    case SRH_PRIM_DISK: hipLaunchKernelGGL(k_prep_views<SRH_PRIM_DISK>, grid, block, 0, st, Fs, s); break;
+    case SRH_PRIM_PLANE: hipLaunchKernelGGL(k_prep_views<SRH_PRIM_PLANE>, grid, block, 0, st, Fs, s); break;
+    case SRH_PRIM_SPHERE: hipLaunchKernelGGL(k_prep_views<SRH_PRIM_SPHERE>, grid, block, 0, st, Fs, s); break;
+    default: hipLaunchKernelGGL(k_prep_views<SRH_PRIM_TRIANGLE>, grid, block, 0, st, Fs, s); break;
+  }
+}
+
+__device__ __forceinline__ void prep_record64(const SegDev& S, int type, int i, const double o[3], bool tch, double* R) {
   double nh[3] = {0, 0, 0};
-  if (S.type != SRH_PRIM_SPHERE) {
+  if (type != SRH_PRIM_SPHERE) {
     // ops.normalize: divide by the 4-D length, by 1 if that is zero (numpy/ops.py:18-26)
     const float* q = S.normal + 4 * (size_t)i;
     const double v[4] = {(double)q[0], (double)q[1], (double)q[2], (double)q[3]};
@@ -175,7 +214,7 @@ __device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tc
     if (!(fabs(len) > 0.0)) len = 1.0;
     nh[0] = v[0] / len; nh[1] = v[1] / len; nh[2] = v[2] / len;
   }
-  if (S.type == SRH_PRIM_SPHERE) {
+  if (type == SRH_PRIM_SPHERE) {
     const float* c = S.pos + 4 * (size_t)i;
     const double r = (double)S.radius[i];
     const double oc[3] = {o[0] - (double)c[0], o[1] - (double)c[1], o[2] - (double)c[2]};
@@ -184,18 +223,18 @@ __device__ void prep_record64(const SegDev& S, int i, const double o[3], bool tc
     return;
   }
   // point on the plane: pos, or vertex 0 of the triangle (numpy/renderer.py:107)
-  const float* pp = (S.type == SRH_PRIM_TRIANGLE) ? S.face + 12 * (size_t)i : S.pos + 4 * (size_t)i;
+  const float* pp = (type == SRH_PRIM_TRIANGLE) ? S.face + 12 * (size_t)i : S.pos + 4 * (size_t)i;
   const double p[3] = {(double)pp[0], (double)pp[1], (double)pp[2]};
   // dist - n^.eye (numpy/renderer.py:62,69)
   const double dist = (p[0] * nh[0] + p[1] * nh[1]) + p[2] * nh[2];
   const double neye = (nh[0] * o[0] + nh[1] * o[1]) + nh[2] * o[2];
   R[0] = nh[0]; R[1] = nh[1]; R[2] = nh[2];
   R[3] = dist - neye;
-  if (S.type == SRH_PRIM_DISK) {
+  if (type == SRH_PRIM_DISK) {
     const double r = (double)S.radius[i];
     R[4] = o[0] - p[0]; R[5] = o[1] - p[1]; R[6] = o[2] - p[2];
     R[7] = r * r;
-  } else if (S.type == SRH_PRIM_TRIANGLE) {
+  } else if (type == SRH_PRIM_TRIANGLE) {
     const float* f = S.face + 12 * (size_t)i;
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -783,9 +822,7 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   }
 
   for (int s = 0; s < F.nseg && !abl_skip_binning; ++s) {
-    const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64,
-                       (float*)S.rec32);
+    launch_prep(F, s, st);
   }
   if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
 #if !SRH_FUSE_BIN
@@ -894,8 +931,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
       int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, wso + head + (size_t)v * one, one, &F, &Lo);
       if (rc) return rc;
       for (int s = 0; s < F.nseg; ++s) {
-        const SegDev& S = F.seg[s];
-        hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+        launch_prep(F, s, st);
       }
       const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
       hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, images + (size_t)v * rows * F.img_stride,
@@ -962,7 +998,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   const size_t ncount = (size_t)kCounterPad + (size_t)F0.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
   for (int s = 0; s < F0.nseg; ++s)
-    hipLaunchKernelGGL(k_prep_views, dim3((F0.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, Fs, s);
+    launch_prep_views(F0, Fs, s, V, st);
 #if !SRH_FUSE_BIN
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)F0.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, Fs);
 #endif
@@ -1031,8 +1067,7 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   hipStream_t st = (hipStream_t)stream;
   // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
   for (int s = 0; s < F.nseg; ++s) {
-    const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64, (float*)S.rec32);
+    launch_prep(F, s, st);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
   const ShadowLayout SL = shadow_layout_for(objects, F.W, F.H, F.nlights);
@@ -1077,7 +1112,7 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   const size_t ncount = (size_t)kCounterPad + (size_t)T.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);
   for (int s = 0; s < T.nseg; ++s)
-    hipLaunchKernelGGL(k_prep_views, dim3((T.seg[s].count + kBinBlock - 1) / kBinBlock, V), dim3(kBinBlock), 0, st, frames, s);
+    launch_prep_views(T, frames, s, V, st);
 #if !SRH_FUSE_BIN
   hipLaunchKernelGGL(k_bin_count_views, dim3((unsigned)(((size_t)T.total * kCountLanes + kBinBlock - 1) / kBinBlock), V), dim3(kBinBlock), 0, st, frames);
 #endif
@@ -1112,9 +1147,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   hipStream_t st = (hipStream_t)stream;
   // the workspace may have served other frames since the forward pass: rebuild the fp64 records (no binning)
   for (int s = 0; s < F.nseg; ++s) {
-    const SegDev& S = F.seg[s];
-    hipLaunchKernelGGL(k_prep, dim3((S.count + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, st, F, s, (double*)S.rec64,
-                       (float*)S.rec32);
+    launch_prep(F, s, st);
   }
   const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
   if (params->ev_start) (void)hipEventRecord((hipEvent_t)params->ev_start, st);
