@@ -89,6 +89,10 @@ constexpr int kCountLanes = SRH_COUNT_LANES;
 // has only a wave or two per SIMD.
 // The tiles of primitive gidx's box that its reject shape really reaches: kLanes lanes share the box (lane `sub` takes
 // tiles sub, sub + kLanes, ...).
+#ifndef SRH_BIN_CLAIMS
+#define SRH_BIN_CLAIMS 4
+#endif
+constexpr int kClaims = SRH_BIN_CLAIMS;
 template <int kLanes>
 __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, int first, const float* rec32, int gidx,
                                           int sub, int tx0, int ty0, int tx1, int ty1) {
@@ -96,24 +100,25 @@ __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, 
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const RectTest T(type, rec32, F.near_clip > 0.0);
   // pass 1, arithmetic only: bit k of `mask` = tile k of the box (row-major) is reached
+  const uint32_t inv_nx = 65536u / (uint32_t)nx + 1u;            // k / nx == (k * inv_nx) >> 16 for k < 64, nx <= 64
   uint64_t mask = 0;
   for (int k = sub; k < n; k += kLanes) {
-    const int tx = tx0 + k % nx, ty = ty0 + k / nx;
+    const int dy = (int)(((uint32_t)k * inv_nx) >> 16);
+    const int tx = tx0 + (k - dy * nx), ty = ty0 + dy;
     const double pc0 = tx * kTile - F.bin_pad, pr0 = F.row0 + ty * kTile - F.bin_pad;
     const double pc1 = fmin(tx * kTile + kTile - 1, (double)(F.W - 1)) + F.bin_pad;
     const double pr1 = fmin(F.row0 + ty * kTile + kTile - 1, (double)(F.row1 - 1)) + F.bin_pad;
     if (T.reaches(pc0, pc1, pr0, pr1)) mask |= 1ull << k;
   }
-  // pass 2: the slot claimed in a bin's counter is the entry's place in the bin's fixed-capacity list.  Four claims
+  // pass 2: the slot claimed in a bin's counter is the entry's place in the bin's fixed-capacity list.  kClaims claims
   // at a time, so that their round trips overlap instead of adding up (a thread owns ~6 bins on average).
   const uint32_t cap = (uint32_t)F.bin_cap;
   uint32_t* slots = F.entries + (size_t)seg * F.ntiles_pad * cap;
-  const uint32_t inv_nx = 65536u / (uint32_t)nx + 1u;            // k / nx == (k * inv_nx) >> 16 for k < 64, nx <= 64
   int over = 0;
   while (mask) {
-    uint32_t tile[4], slot[4];
+    uint32_t tile[kClaims], slot[kClaims];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kClaims; ++j) {
       tile[j] = 0xffffffffu;
       if (mask) {
         const uint32_t k = (uint32_t)__builtin_ctzll(mask);
@@ -124,7 +129,7 @@ __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, 
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < kClaims; ++j)
       if (tile[j] != 0xffffffffu) {
         if (slot[j] < cap) slots[(size_t)tile[j] * cap + slot[j]] = (uint32_t)gidx;
         else over = 1;
