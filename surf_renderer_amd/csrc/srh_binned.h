@@ -356,7 +356,9 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
     // candidate iff q <= 0; tested as q - 2^-22 < 0 (a superset) so that the sign bit decides
     const float dr = rf - R[1];
     f32x2 q[2];
-    if (R[11] > 0.0f) {                                     // principal-axes form (wave-uniform branch)
+    // principal-axes form iff R[11] > 0 (conic_record stores 0 or a positive finite scale there): compared on the bit
+    // pattern, so that the wave-uniform branch is a scalar compare and not a v_cmp plus mask arithmetic per entry
+    if (__float_as_int(R[11]) > 0) {
       const float eydr = R[3] * dr, exdr = R[2] * dr;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {

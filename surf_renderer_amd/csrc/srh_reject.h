@@ -277,7 +277,7 @@ template <int N>
 __device__ __forceinline__ void ellipse_reject(const float* __restrict__ R, const float (&cf)[N], float rf,
                                                float (&q)[N]) {
   const float dr = rf - R[1];
-  if (R[11] > 0.0f) {                                     // principal-axes form (wave-uniform branch)
+  if (__float_as_int(R[11]) > 0) {                        // principal-axes form (wave-uniform: a scalar compare on the bits)
     const float eydr = R[3] * dr, exdr = R[2] * dr;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
