@@ -442,23 +442,29 @@ __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __r
   if (n_all <= part) return;
   const uint32_t n = (n_all - part + WPT - 1) / WPT;
   RejectRecord<TYPE> A, B;
-  const float* base = S.rec32;
   const int first = S.first;
-  auto entry = [&](uint32_t k) { return (int)list[min(k, n - 1) * WPT + part]; };
+  // 32-bit byte offsets, so that hipcc addresses list words and records as base + scalar offset (`s_load ... sN`)
+  // instead of building 64-bit addresses with five scalar instructions each
+  const char* list_c = reinterpret_cast<const char*>(list) + 4u * part;
+  const char* base_c = reinterpret_cast<const char*>(S.rec32);
+  auto entry = [&](uint32_t k) { return *reinterpret_cast<const int*>(list_c + min(k, n - 1) * (4u * WPT)); };
+  auto record = [&](int g) {
+    return reinterpret_cast<const float*>(base_c + (uint32_t)(g - first) * (uint32_t)(4 * kRec32Stride[TYPE]));
+  };
   auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, kOrdMask); };
   int gA = entry(0);
   int gB = entry(1);
-  A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
+  A.load(record(gA));
   for (uint32_t i = 0; i < n; i += 2) {
     // B <- entry i+1 (clamped: reloading a valid record is harmless), then the list word of entry i+2
-    B.load(base + (size_t)(gB - first) * kRec32Stride[TYPE]);
+    B.load(record(gB));
     const int gNow = gA;
     gA = entry(i + 2);
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, the arithmetic below (hipcc would sink them)
     op(A, gNow, field(i));
     if (i + 1 >= n) break;
     __builtin_amdgcn_sched_barrier(0);
-    A.load(base + (size_t)(gA - first) * kRec32Stride[TYPE]);
+    A.load(record(gA));
     const int gNext = gB;
     gB = entry(i + 3);
     __builtin_amdgcn_sched_barrier(0);
