@@ -72,3 +72,27 @@ def test_pipeline_frame_matches_render():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(image.cpu().numpy(), want["image"].cpu().numpy())
     np.testing.assert_array_equal(depth.cpu().numpy(), want["depth"].cpu().numpy())
+
+
+@pytest.mark.parametrize("kw", [dict(schedule="stages", render_streams=2), dict(schedule="stages", render_streams=1),
+                                dict(schedule="stages", render_streams=2, prioritise_render=False),
+                                dict(schedule="frames", rotate=2)])
+def test_other_schedules_equal_the_eager_frame(kw):
+    """The stage schedule (every frame's binning on one stream, the render kernels on others, tied by events; the
+    binning and the render halves of a frame are separate graphs -- SrhParams.stages) and rotating scratch / slab
+    pairs give the eager frame bit for bit, with timing-event frames (eager launches) mixed in."""
+    from surf_renderer_amd import _lib
+    pipe = _pipeline(_scene(), n_inflight=3, graphs=True, strict_graphs=True, mode="binned", **kw)
+    for _ in range(5):
+        pipe.submit()
+    pipe.poison()
+    pairs = []
+    for i in range(13):
+        ev = _lib.EventPair() if i % 5 == 2 else None
+        if ev:
+            pairs.append(ev)
+        pipe.submit(ev)
+    assert pipe.verify() == min(pipe.n, 13)
+    for ev in pairs:
+        assert 0.0 < ev.elapsed_ms() < 1000.0
+        ev.close()

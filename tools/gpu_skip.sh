@@ -1,5 +1,7 @@
 #!/bin/bash
-for v in base bt4 base bt4; do
-if [ $v = base ]; then unset SRH_LIB; else export SRH_LIB=$PWD/build/abl/$v.so; fi
-echo "== $v"; timeout -k 10 200 python tools/prof_bwd_shadow.py --cases bwd_mesh_resident_tch --steps 40 2>&1 | tail -1 | cut -c1-220
-done
+run() { timeout -k 10 120 python bench.py --no-cpu-baseline $2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $2', '-> ms/step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), d['config']['check'][:14])"; }
+for i in 1 2 3; do run frames "--steps 20 --warmup 5"; done
+for i in 1 2 3; do run stages "--schedule stages --steps 20 --warmup 5"; done
+for i in 1 2; do run stages-flat "--schedule stages --flat-priority --steps 20 --warmup 5"; done
+run stages "--schedule stages"
+run stages3 "--schedule stages --render-streams 3 --inflight 4"
