@@ -68,9 +68,11 @@ def parse():
                     help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
                          "overlap the render kernel of another.  Default 3 (measured: 1 -> 5.3k, 2 -> 7.7k, 3 -> 8.1k, "
                          "4 -> 7.1k frames/s on one MI355X)")
-    ap.add_argument("--schedule", default="frames", choices=["frames", "stages", "render-only", "bin-only"],
+    ap.add_argument("--schedule", default="auto", choices=["auto", "frames", "stages", "render-only", "bin-only"],
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
-                         "one stream for every frame's binning kernels, one for every frame's render kernel")
+                         "one stream for every frame's binning kernels, --render-streams for the render kernels (same "
+                         "steady state, 2 %% faster over a 20-step timed region: the streams do not start in lockstep); "
+                         "auto = stages when the frames are binned and graphs are on, else frames")
     ap.add_argument("--render-streams", type=int, default=2, help="--schedule stages: streams the render kernels alternate over")
     ap.add_argument("--bin-priority", action="store_true", help="--schedule stages: the binning stream gets the higher priority")
     ap.add_argument("--flat-priority", action="store_true", help="--schedule stages: do not raise the render streams' priority")
@@ -384,7 +386,7 @@ def main():
         # the start of a pipeline that a short run has only a few frames to amortise
         events = [_lib.EventPair() if i % ev_every == ev_every // 2 else None for i in range(args.steps)]
     counter = [0]
-    pipe = None
+    pipe, schedule = None, "frames"
 
     graphs = {}
     # Graph replay is the default on the single-process path only; --graph on asks for it with a process group too.
@@ -561,10 +563,26 @@ def main():
         if os.environ.get("SRH_BENCH_ONE_SLAB"):     # diagnostic: every frame in flight writes the same output slab
             one_slab = [torch.empty((r1 - r0, 4 * W), dtype=torch.float32, device=device)] * \
                 (n_str * int(os.environ.get("SRH_BENCH_ROTATE", "1")))
-        pipe = FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
-                             slabs=one_slab, strict_graphs=args.graph == "on", schedule=args.schedule,
-                             render_streams=args.render_streams, prioritise_render=not args.flat_priority,
-                             prioritise_bin=args.bin_priority, rotate=int(os.environ.get("SRH_BENCH_ROTATE", "1")))
+        rotate = int(os.environ.get("SRH_BENCH_ROTATE", "1"))
+
+        def make_pipe(schedule):
+            return FramePipeline(buf, cam, rows=(r0, r1), n_inflight=n_str, mode=args.mode, graphs=graph_state["on"],
+                                 slabs=one_slab, strict_graphs=args.graph == "on", schedule=schedule,
+                                 render_streams=args.render_streams, prioritise_render=not args.flat_priority,
+                                 prioritise_bin=args.bin_priority, rotate=rotate)
+        schedule = args.schedule
+        if schedule == "auto":
+            schedule = "frames"
+            if args.mode in ("auto", "binned") and graph_state["on"] and rotate == 1:
+                try:                                   # the library refuses split frames that are not binned
+                    pipe = make_pipe("stages")
+                    schedule = "stages" if pipe.use_graphs else "frames"
+                except (ValueError, _lib.SrhError) as exc:
+                    print(f"[bench] stage schedule not available ({exc}); whole frames per stream", file=sys.stderr)
+            if schedule == "frames":
+                pipe = make_pipe("frames")
+        else:
+            pipe = make_pipe(schedule)
         graph_state["on"] = pipe.use_graphs
         graph_state["captured"] = pipe.captured
         n_buf, slabs = n_str, pipe.slabs
@@ -766,7 +784,7 @@ def main():
             "config": {"workload": "BASELINE configs[4]: 100k synthetic disk splats, 2048x2048, forward render, "
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
-                       "frames_in_flight": n_str, "schedule": args.schedule if pipe is not None else "frames",
+                       "frames_in_flight": n_str, "schedule": schedule if pipe is not None else "frames",
                        "launch": f"hipGraph replay ({graph_state['captured']} graphs)"
                                  if graph_state["on"] and graph_state["captured"] else "eager",
                        "warmup_steps_run": warm_steps, "warmup_ms_run": warm_ms,
@@ -791,7 +809,7 @@ def main():
                          "algorithmic_bytes": alg_bytes,
                          # `kernel_ms` is one launch's duration WHILE `concurrent_launches` frames share the GPU (their
                          # render kernels overlap); per unit of job time the kernel moves alg_bytes every ms_per_step
-                         "concurrent_launches": n_str,
+                         "concurrent_launches": (args.render_streams if (pipe is not None and schedule == "stages") else n_str),
                          "achieved_per_job_time": alg_bytes / (elapsed / args.steps) / 1e9,
                          "note": "the kernel is bound by vector-instruction issue, not by HBM; see valu_issue"},
             # SURVEY 8d's figure: algorithmic flops of ALL (pixel, primitive) pairs per second against the fp32 vector
