@@ -1,8 +1,10 @@
 #!/bin/bash
-run() { timeout -k 10 120 python bench.py --no-cpu-baseline $2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$1] $2', '-> ms/step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), d['config']['schedule'], d['config']['check'][:14])"; }
-for i in 1 2 3; do run auto "--steps 20 --warmup 5"; done
-run auto ""
-run frames "--schedule frames --steps 20 --warmup 5"
-run small "--prims 2000 --width 256 --height 256 --steps 50"
-run fast "--mode fast --prims 2000 --width 256 --height 256 --steps 50"
-run graphoff "--graph off --steps 50"
+export SRH_BENCH_SINGLE_DEVICE=1 SRH_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
+for P in 2 4; do
+  echo "## P = $P (default slabs)"
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port $((29600+P)) bench.py --gpus $P --steps 16 --warmup 4 2> gpurun_out/mr_$P.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('n_gpus','steps','ms_per_step')}, d['config'].get('rows_per_rank'), '|', d['config'].get('collection'), '|', d['config'].get('check')); print('literal_root0' in d, 'links_measured' in d)"
+  grep -h "check ok\|FAILED\|differs\|Error\|error" gpurun_out/mr_$P.err | head -5
+done
+echo "## P = 2 equal slabs, batched views call"
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 16 --warmup 4 --slabs contiguous 2> gpurun_out/mr_2c.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('n_gpus','steps','ms_per_step')}, d['config'].get('rows_per_rank'), '|', d['config'].get('collection'), '|', d['config'].get('check'))"
+grep -h "check ok\|FAILED\|differs" gpurun_out/mr_2c.err | head -3
