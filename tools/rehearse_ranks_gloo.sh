@@ -1,4 +1,7 @@
 #!/bin/bash
+# Multi-rank schedule of bench.py rehearsed on ONE GPU: gloo process group, every rank on device 0 (RCCL refuses two ranks
+# on one device).  Rates are meaningless; what it checks is that the P-rank path runs with the real kernels and that
+# every collected / assembled frame equals the eager render bit for bit.
 export SRH_BENCH_SINGLE_DEVICE=1 SRH_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 for P in 2 4; do
   echo "## P = $P (default slabs)"
