@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import json
 import os
-from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -287,30 +286,8 @@ def scene_to_numpy(scene: Dict[str, Any], dtype=np.float64, round_fp32: bool = F
 
 
 # ----------------------------------------------------------------------------------------
-# camera frame (host side, fp64)
+# camera helpers (host side)
 # ----------------------------------------------------------------------------------------
-@dataclass
-class CameraFrame:
-    """Everything the ray generator needs, in fp64, derived once per frame on the host.
-
-    Follows numpy/renderer.py:145-169 and numpy/ops.py:88-115 including their quirks: the basis
-    is y = up/|up|, z = (eye-at)/|eye-at|, x = cross(y, z) *not* re-normalised, and
-    list-typed ``at`` / ``up`` pass through float32 first, ``up`` is also normalised there (Q11).
-    """
-    width: int
-    height: int
-    eye: np.ndarray          # (4,)  homogeneous, as given
-    origin: np.ndarray       # (3,)  ray origin used for intersections = eye[:3]
-    bx: np.ndarray           # (3,)  image-plane x axis (not unit in general)
-    by: np.ndarray           # (3,)
-    bz: np.ndarray           # (3,)
-    half_w: float            # w/2 = tan(fovy/2) * f * W/H
-    half_h: float            # h/2 = tan(fovy/2) * f
-    focal: float
-    near: float
-    far: float
-
-
 def unit_up(given, up64: np.ndarray) -> np.ndarray:
     """The camera's y axis, up / |up| (numpy/ops.py:109).  A list-typed ``up`` is a float32 array at that point
     (:99), so norm and division happen in float32 -- repeated here with the same numpy calls -- and everything after
@@ -322,40 +299,3 @@ def unit_up(given, up64: np.ndarray) -> np.ndarray:
     return up64 / np.linalg.norm(up64, 2)
 
 
-def camera_frame(camera: Dict[str, Any]) -> CameraFrame:
-    vp = [int(t) for t in _np(camera["viewport"]).ravel()]
-    width, height = vp[2] - vp[0], vp[3] - vp[1]
-    if width <= 0 or height <= 0:
-        raise ValueError(f"empty viewport {vp}")
-    fovy = float(_np(camera["fovy"]).ravel()[0])
-    focal = float(_np(camera["focal_length"]).ravel()[0])
-    half_h = np.tan(fovy / 2) * 2 * focal / 2
-    half_w = (np.tan(fovy / 2) * 2 * focal * (width / float(height))) / 2
-
-    def vec(val, list_is_f32):
-        if hasattr(val, "detach"):
-            return val.detach().cpu().numpy().astype(np.float64)
-        if list_is_f32 and isinstance(val, (list, tuple)):
-            return np.asarray(val, dtype=np.float32).astype(np.float64)
-        return np.asarray(val, dtype=np.float64)
-
-    eye = vec(camera["eye"], False)
-    at = vec(camera["at"], True)
-    up = vec(camera["up"], True)
-    if up.size == 4:
-        if up[3] != 0:
-            raise ValueError("camera.up must be a direction (w == 0)")
-        up = up[:3]
-    if eye.size != 4 or at.size != 4:
-        raise ValueError("camera.eye and camera.at must be homogeneous 4-vectors")
-    z = eye - at
-    z = (z / np.linalg.norm(z, 2))[:3]
-    y = unit_up(camera["up"], up)
-    x = np.cross(y, z)
-    if eye[3] != 1.0:
-        # the reference places the ray origin at eye (w kept) while the view matrix uses eye/w;
-        # both coincide only for w == 1, which is what every scene uses.
-        raise ValueError("camera.eye must have w == 1")
-    return CameraFrame(width=width, height=height, eye=eye, origin=eye[:3].copy(), bx=x, by=y, bz=z,
-                       half_w=float(half_w), half_h=float(half_h), focal=focal,
-                       near=float(_np(camera["near"]).ravel()[0]), far=float(_np(camera["far"]).ravel()[0]))

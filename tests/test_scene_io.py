@@ -96,18 +96,6 @@ def test_scene_to_numpy_copies_and_rounds():
         sio.scene_to_numpy({**sc, "objects": {"obj": []}})
 
 
-def test_camera_frame_quirks():
-    cam = synthetic.demo_scene(64, 48)["camera"]
-    fr = sio.camera_frame(cam)
-    assert (fr.width, fr.height) == (64, 48)
-    np.testing.assert_allclose(np.linalg.norm(fr.by), 1.0)
-    assert abs(np.linalg.norm(fr.bx) - 1.0) > 1e-3          # Q1: x = cross(y, z) is not re-normalised
-    np.testing.assert_allclose(fr.half_w / fr.half_h, 64 / 48)
-    bad = dict(cam, eye=[0, 1, 10, 2.0])
-    with pytest.raises(ValueError):
-        sio.camera_frame(bad)
-
-
 def test_disk_cloud_is_seeded_and_fp32_representable():
     a = synthetic.disk_cloud_scene(500, 32, 32)
     b = synthetic.disk_cloud_scene(500, 32, 32)
