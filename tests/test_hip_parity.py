@@ -226,6 +226,15 @@ def test_crowded_bins_overflow_to_the_frame_wide_list():
         d["pos"][1000:, :3] = rng.uniform(-1.0, 1.0, size=(500, 3)).astype(np.float32)
         ref = _modes_identical(scene, modes=("exact", "binned"))
         assert np.isfinite(ref["depth"]).any()
+        if w == 512:                                      # the same through the batched entry point (per-view bins)
+            from surf_renderer_amd import render_views
+            cams = [dict(scene["camera"], eye=[0.3 * k, 0.0, 4.0, 1.0]) for k in range(3)]
+            batch = render_views(scene, cams, device="cuda:0")
+            torch.cuda.synchronize()
+            for i, cam in enumerate(cams):
+                single = _render({**scene, "camera": cam}, mode="exact")
+                for k in ("nearest", "depth", "image"):
+                    np.testing.assert_array_equal(batch[k][i].cpu().numpy(), single[k], err_msg=f"crowded view {i}: {k}")
 
 
 def test_render_views_equals_per_view_render():

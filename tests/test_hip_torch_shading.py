@@ -224,6 +224,15 @@ def test_binned_shadow_pass_equals_all_pairs_bit_for_bit():
     lp[0, :3] = (p0 + 0.05 * n0 / np.linalg.norm(n0)).astype(np.float32)
     mixed["lights"]["pos"] = lp
     cases.append((mixed, {}))
+    # a crowd: 1000 discs in a patch that covers a few tiles of every light's view -> those bins are full (64 slots
+    # for 1500 primitives on 2048^2 light views) and the discs that do not fit go to the frame-wide list
+    crowd = _with_torch_inputs(synthetic.disk_cloud_scene(1500, 128, 96, radius=0.01, seed=23))
+    rng = np.random.RandomState(5)
+    pos = np.asarray(crowd["objects"]["disk"]["pos"], dtype=np.float32).copy()
+    pos[:1000, :2] = rng.uniform(-0.03, 0.03, size=(1000, 2)).astype(np.float32)
+    pos[:1000, 2] = rng.uniform(-0.5, 0.5, size=1000).astype(np.float32)
+    crowd["objects"]["disk"]["pos"] = pos
+    cases.append((crowd, {"double_sided": True}))
     shadowed = 0
     for scene, kw in cases:
         (img_b, vis_b, depth), (img_a, vis_a, _) = _shadow_both_ways(scene, **kw)
