@@ -446,10 +446,11 @@ __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __r
   // 32-bit byte offsets, so that hipcc addresses list words and records as base + scalar offset (`s_load ... sN`)
   // instead of building 64-bit addresses with five scalar instructions each
   const char* list_c = reinterpret_cast<const char*>(list) + 4u * part;
-  const char* base_c = reinterpret_cast<const char*>(S.rec32);
+  // the batch's first global index folded into the base (the loads only ever see base + offset of a real record)
+  const char* base_c = reinterpret_cast<const char*>(S.rec32) - (size_t)first * (size_t)(4 * kRec32Stride[TYPE]);
   auto entry = [&](uint32_t k) { return *reinterpret_cast<const int*>(list_c + min(k, n - 1) * (4u * WPT)); };
   auto record = [&](int g) {
-    return reinterpret_cast<const float*>(base_c + (uint32_t)(g - first) * (uint32_t)(4 * kRec32Stride[TYPE]));
+    return reinterpret_cast<const float*>(base_c + (uint32_t)g * (uint32_t)(4 * kRec32Stride[TYPE]));
   };
   auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, kOrdMask); };
   int gA = entry(0);
