@@ -43,20 +43,29 @@ def stale() -> bool:
 def build_lib(force: bool = False, verbose: bool = False, extra: List[str] = ()) -> str:
     """Compile libsrh.so if missing or older than its sources; returns its path."""
     if force or stale():
-        # compile next to the target and rename into place: several ranks of one job may find the library missing at
-        # the same time, and none of them may ever dlopen a half-written file
-        tmp = f"{LIB_PATH}.tmp{os.getpid()}"
-        cmd = command(list(extra), out=tmp)
-        if verbose:
-            print(" ".join(cmd).replace(tmp, LIB_PATH), file=sys.stderr)
-        proc = subprocess.run(cmd, capture_output=True, text=True)
-        if proc.returncode != 0:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-            raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
-        os.replace(tmp, LIB_PATH)
-        if verbose and proc.stderr:
-            print(proc.stderr, file=sys.stderr)
+        # Compile next to the target and rename into place: several ranks of one job may find the library missing at
+        # the same time, and none of them may ever dlopen a half-written file.  One process compiles (file lock), into a
+        # FIXED temporary name: hipcc derives the code object's identity from the output path, so a name with the pid in
+        # it gave every build another sha256 (bench.py quotes the hash the PMC counters were taken with).
+        import fcntl
+        with open(LIB_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():                   # somebody else may have built it while we waited
+                    tmp = LIB_PATH + ".build"
+                    cmd = command(list(extra), out=tmp)
+                    if verbose:
+                        print(" ".join(cmd).replace(tmp, LIB_PATH), file=sys.stderr)
+                    proc = subprocess.run(cmd, capture_output=True, text=True)
+                    if proc.returncode != 0:
+                        if os.path.exists(tmp):
+                            os.remove(tmp)
+                        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+                    os.replace(tmp, LIB_PATH)
+                    if verbose and proc.stderr:
+                        print(proc.stderr, file=sys.stderr)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
