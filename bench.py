@@ -771,6 +771,15 @@ def main():
         default_workload = (M, W, H, world) == (100_000, 2048, 2048, 1) and args.mode in ("auto", "binned") \
             and not args.as_rank
         pmc = load_pmc() if default_workload else None
+        lib_match = "unknown"
+        if pmc:
+            try:
+                import hashlib
+                with open(_lib.lib_path(), "rb") as fh:
+                    same = hashlib.sha256(fh.read()).hexdigest() == pmc["lib_sha256"]
+                lib_match = "the library this run loaded" if same else "NOT the library this run loaded"
+            except Exception:                               # noqa: BLE001
+                pass
         valu_n = pmc["valu_wave_instr"] if pmc else 0.0
         ginstr_s = valu_n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
@@ -805,7 +814,8 @@ def main():
                          "traffic": pmc["traffic_bytes"] if pmc else None,
                          "traffic_source": (f"profiles/r02_pmc.json: rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (separate "
                                             f"passes, per launch), taken at commit {pmc['commit']}, libsrh.so sha256 "
-                                            f"{str(pmc['lib_sha256'])[:12]}; not re-measured by this run") if pmc else None,
+                                            f"{str(pmc['lib_sha256'])[:12]} ({lib_match}); not re-measured by this run")
+                         if pmc else None,
                          "kernel": "render kernel of rank 0", "kernel_ms": kernel_ms,
                          "algorithmic_bytes": alg_bytes,
                          # `kernel_ms` is one launch's duration WHILE `concurrent_launches` frames share the GPU (their
