@@ -215,7 +215,7 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
  * view v starts v * rows * row_stride elements after view 0 in images (n_views,rows,W,3), depths (n_views,rows,W)
  * and nearests (may be NULL).  Every kernel of the
  * frame pipeline is launched once for the whole batch (the view is a grid dimension), so small views cost neither
- * six launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
+ * three launches each nor an idle GPU.  Results equal srh_render_fwd per view.  The workspace must hold
  * srh_workspace_bytes_views(...) bytes.  Calls on one device are serialised on that device's staging ring. */
 size_t srh_workspace_bytes_views(const SrhObjects* objects, int32_t width, int32_t height, int32_t n_views);
 int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects* objects, const SrhLights* lights,
