@@ -268,6 +268,13 @@ __device__ __forceinline__ float float_above(double t) { return (float)t * 1.000
 template <bool TCH>
 __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, const double d[3], double& best,
                                                int& besti) {
+  if (F.nseg == 1) {
+    // one object batch (the common scene): type and base are wave-uniform, the intersection is chosen by a scalar branch
+    const int type = F.seg[0].type;
+    const double* R = F.seg[0].rec64 + (size_t)(gidx - F.seg[0].first) * kRec64Stride[type];
+    resolve_lex(F, hit_any64(type, R, F.o, d, TCH), gidx, best, besti);
+    return;
+  }
   const int s = segment_of(F, gidx);
   int type = F.seg[0].type, first = F.seg[0].first;
   const double* base = F.seg[0].rec64;
@@ -289,14 +296,16 @@ struct FrontRecord {
   __device__ __forceinline__ void fetch(const FrameDev& F, int gidx) {
     g = gidx;
     const int gs = max(gidx, 0);
-    const int s = segment_of(F, gs);
     int first = F.seg[0].first;
     const double* base = F.seg[0].rec64;
     const int32_t* mat = F.seg[0].mat;
     type = F.seg[0].type;
+    if (F.nseg > 1) {                       // one batch: everything above is already right (and wave-uniform)
+      const int s = segment_of(F, gs);
 #pragma unroll
-    for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
-      if (s == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec64; mat = F.seg[i].mat; }
+      for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+        if (s == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec64; mat = F.seg[i].mat; }
+    }
     const int li = gs - first;
     const int stride = type == SRH_PRIM_DISK ? kRec64Stride[0] : type == SRH_PRIM_PLANE ? kRec64Stride[1]
                      : type == SRH_PRIM_SPHERE ? kRec64Stride[2] : kRec64Stride[3];
@@ -313,6 +322,14 @@ struct FrontRecord {
     m = clampi(mat[li], 0, F.nmat - 1);
   }
   __device__ __forceinline__ double hit(const FrameDev& F, const double d[3]) const {
+    if (F.nseg == 1) {                      // wave-uniform type: a scalar branch picks the intersection
+      switch (F.seg[0].type) {
+        case SRH_PRIM_DISK: return hit_disk64(v, d);
+        case SRH_PRIM_PLANE: return hit_plane64(v, d);
+        case SRH_PRIM_SPHERE: return TCH ? hit_sphere64_tch(v, d) : hit_sphere64(v, d);
+        default: return hit_triangle64(R, F.o, d);
+      }
+    }
     switch (type) {
       case SRH_PRIM_DISK: return hit_disk64(v, d);
       case SRH_PRIM_PLANE: return hit_plane64(v, d);
