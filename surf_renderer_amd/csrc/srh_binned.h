@@ -663,6 +663,10 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
 // Global primitive index of the entry with ordinal `ord` (per lane) in the tile's lists; -1 if out of range.
 __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, uint32_t ord) {
   const TileLists L{F, tile};
+  if (F.nseg == 1 && L.count(0, 0) == 0) {          // one batch, nothing frame-wide: the ordinal is the bin-list position
+    const uint32_t n = L.count(0, 1);
+    return ord < n ? (int)L.list(0, 1)[min(ord, n - 1)] : -1;
+  }
   int g = -1;
   bool done = false;
   for (int s = 0; s < F.nseg; ++s) {
