@@ -337,12 +337,20 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     rgb[0] = rgb[1] = rgb[2] = tonemap_f32(F, 0.0);
     return;
   }
-  int s = 0;
+  // the winner's batch: with one batch in the scene (wave-uniform test) nothing has to be selected per lane
+  int seg_type = F.seg[0].type, seg_first = F.seg[0].first;
+  const float* seg_pos = F.seg[0].pos;
+  const double* seg_rec64 = F.seg[0].rec64;
+  const int32_t* seg_mat = F.seg[0].mat;
+  if (F.nseg > 1) {
 #pragma unroll
-  for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
-    if (i < F.nseg && win >= F.seg[i].first) s = i;
-  const SegDev& S = F.seg[s];
-  const int li = win - S.first;
+    for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
+      if (i < F.nseg && win >= F.seg[i].first) {
+        seg_type = F.seg[i].type; seg_first = F.seg[i].first; seg_pos = F.seg[i].pos; seg_rec64 = F.seg[i].rec64;
+        seg_mat = F.seg[i].mat;
+      }
+  }
+  const int li = win - seg_first;
   const double* org = origin ? origin : F.o;     // orthographic rays start on the image plane, not at the eye
   // From here on the arithmetic feeds only the fp32 image (2e-7 + 2e-6 |x| against the reference): multiply-adds are
   // written as explicit FMAs -- every kernel that inlines this function then rounds identically, so the render modes
@@ -350,14 +358,14 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
   const double p[3] = {__builtin_fma(z, d[0], org[0]), __builtin_fma(z, d[1], org[1]), __builtin_fma(z, d[2], org[2])};
 
   double n[3];
-  if (S.type == SRH_PRIM_SPHERE) {
+  if (seg_type == SRH_PRIM_SPHERE) {
     // (p - c) / |p - c|, zero where the ray's line misses the sphere (:45-47); p == c gives nan as there
-    const float* c = S.pos + 4 * (size_t)li;
+    const float* c = seg_pos + 4 * (size_t)li;
     const double v[3] = {p[0] - (double)c[0], p[1] - (double)c[1], p[2] - (double)c[2]};
     const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
     const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : (0.0 / len2);
     bool ok;
-    (void)hit_sphere64(S.rec64 + 4 * (size_t)li, d, &ok);
+    (void)hit_sphere64(seg_rec64 + 4 * (size_t)li, d, &ok);
     // the torch backend normalises with its eps: v / sqrt(|v|^2 + 3e-10) (torch/utils.py:131-135)
     const double inv_t = (len2 + 3.0e-10 > 0.0) ? rsqrt_newton(len2 + 3.0e-10) : 1.0;
 #pragma unroll
@@ -366,10 +374,10 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     n[0] = hint->n[0]; n[1] = hint->n[1]; n[2] = hint->n[2];
   } else {
     // unit normal as k_prep normalised it (ops.normalize, zero vectors stay zero, numpy/ops.py:18-26)
-    const double* R = S.rec64 + (size_t)li * kRec64Stride[S.type];
+    const double* R = seg_rec64 + (size_t)li * kRec64Stride[seg_type];
     n[0] = R[0]; n[1] = R[1]; n[2] = R[2];
   }
-  const int m = (hint && hint->g == win) ? hint->m : clampi(S.mat[li], 0, F.nmat - 1);
+  const int m = (hint && hint->g == win) ? hint->m : clampi(seg_mat[li], 0, F.nmat - 1);
   const double alb[3] = {(double)F.albedo[3 * m], (double)F.albedo[3 * m + 1], (double)F.albedo[3 * m + 2]};
   if (aux) {
 #pragma unroll
