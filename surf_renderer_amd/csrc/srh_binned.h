@@ -886,7 +886,14 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   const bool want_aux = F.normal_out || F.pos_out;
   const uint32_t mine = WPT == 1 ? 0xFu : (1u << wave);   // pixels of the quad this wave finishes
   uint32_t has = 0;                           // bit j: pixel j of the quad exists, is mine and has a candidate
+  // a tile nobody reaches (every list empty; the same for all waves of a workgroup that shares the tile) goes straight
+  // to the background stores: no ray set-up, no sweep
+  uint32_t listed = 0;
   {
+    const TileLists L{F, tile};
+    for (int s = 0; s < F.nseg; ++s) listed |= L.count(s, 0) | L.count(s, 1);
+  }
+  if (listed) {
     const int r = min(r_raw, F.row1 - 1);
     QuadState Q;
     Q.rf = (float)r;
