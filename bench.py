@@ -40,6 +40,12 @@ VALU_PEAK_GINSTR_S = 614.4
 PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 
 
+# --schedule auto: the stage schedule is chosen when one frame's render kernel takes at least this many times as long as
+# its binning kernels (measured: config 5, ratio 2.6, stages = frames in steady state and 2 % better over 20 steps; half
+# a frame, ratio 2.0, stages 35 % WORSE -- the prioritised render streams starve the one binning stream)
+STAGES_MIN_RATIO = 2.3
+
+
 def load_pmc():
     """Per-launch PMC counters of the render kernel on the default workload, as collected by tools/collect_pmc.py and
     committed under profiles/ together with the commit and the library hash they were taken at.  None when absent."""
@@ -72,8 +78,9 @@ def parse():
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
                          "one stream for every frame's binning kernels, --render-streams for the render kernels (same "
                          "steady state, 2 %% faster over a 20-step timed region: the streams do not start in lockstep); "
-                         "auto = stages when the frames are binned, graphs are on and at least three frames are in flight, "
-                         "else frames (with one frame in flight the split costs 0.183 instead of 0.150 ms)")
+                         "auto = stages when the frames are binned, graphs are on, at least three frames are in flight and "
+                         "the render kernel of one frame takes at least twice as long as its binning (timed once), "
+                         "else frames")
     ap.add_argument("--render-streams", type=int, default=2, help="--schedule stages: streams the render kernels alternate over")
     ap.add_argument("--bin-priority", action="store_true", help="--schedule stages: the binning stream gets the higher priority")
     ap.add_argument("--flat-priority", action="store_true", help="--schedule stages: do not raise the render streams' priority")
@@ -387,7 +394,7 @@ def main():
         # the start of a pipeline that a short run has only a few frames to amortise
         events = [_lib.EventPair() if i % ev_every == ev_every // 2 else None for i in range(args.steps)]
     counter = [0]
-    pipe, schedule = None, "frames"
+    pipe, schedule, halves = None, "frames", None
 
     graphs = {}
     # Graph replay is the default on the single-process path only; --graph on asks for it with a process group too.
@@ -571,13 +578,39 @@ def main():
                                  slabs=one_slab, strict_graphs=args.graph == "on", schedule=schedule,
                                  render_streams=args.render_streams, prioritise_render=not args.flat_priority,
                                  prioritise_bin=args.bin_priority, rotate=rotate)
+        def halves_ms():
+            """One eager frame's two halves (binning kernels, render kernel), timed alone on the current stream."""
+            ws = buf.new_workspace(W, H)
+            tmp = torch.empty((r1 - r0, 4 * W), dtype=torch.float32, device=device)
+            image, depth = views(tmp)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for it in range(3):                        # two warm passes, the third one is timed
+                if it == 2:
+                    ev[0].record()
+                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None), workspace=ws,
+                                        stages=_lib.STAGE_BIN)
+                if it == 2:
+                    ev[1].record()
+                renderer.render_buffers(buf, cam, rows=(r0, r1), mode=args.mode, out=(image, depth, None), workspace=ws,
+                                        stages=_lib.STAGE_RENDER)
+            ev[2].record()
+            torch.cuda.synchronize(device)
+            return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+
+        halves = None
         schedule = args.schedule
         if schedule == "auto":
+            # The stage schedule serialises every frame's binning on one stream: right when the render kernel is the
+            # long half (config 5: 100 us against 40), wrong for small frames and row slabs, where three binning chains
+            # side by side are what hides their latency.  Decided by timing one frame's halves.
             schedule = "frames"
             if args.mode in ("auto", "binned") and graph_state["on"] and rotate == 1 and n_str >= 3:
                 try:                                   # the library refuses split frames that are not binned
-                    pipe = make_pipe("stages")
-                    schedule = "stages" if pipe.use_graphs else "frames"
+                    bin_ms, render_ms = halves_ms()
+                    halves = {"bin_ms": round(bin_ms, 4), "render_ms": round(render_ms, 4)}
+                    if render_ms >= STAGES_MIN_RATIO * bin_ms:
+                        pipe = make_pipe("stages")
+                        schedule = "stages" if pipe.use_graphs else "frames"
                 except (ValueError, _lib.SrhError) as exc:
                     print(f"[bench] stage schedule not available ({exc}); whole frames per stream", file=sys.stderr)
             if schedule == "frames":
@@ -795,6 +828,7 @@ def main():
                                    "framebuffer row-tiled across ranks + 1 gather",
                        "prims": M, "width": W, "height": H, "lights": 4, "mode": args.mode,
                        "frames_in_flight": n_str, "schedule": schedule if pipe is not None else "frames",
+                       "schedule_probe": halves,
                        "launch": f"hipGraph replay ({graph_state['captured']} graphs)"
                                  if graph_state["on"] and graph_state["captured"] else "eager",
                        "warmup_steps_run": warm_steps, "warmup_ms_run": warm_ms,
