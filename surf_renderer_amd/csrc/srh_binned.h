@@ -296,6 +296,23 @@ struct FrontRecord {
   __device__ __forceinline__ void fetch(const FrameDev& F, int gidx) {
     g = gidx;
     const int gs = max(gidx, 0);
+    if (F.nseg == 1) {                      // one batch: type, stride and bases are wave-uniform
+      const int t0 = F.seg[0].type;
+      type = t0;
+      const int li = gs - F.seg[0].first;
+      R = F.seg[0].rec64 + (size_t)li * kRec64Stride[t0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = R[i];
+      if (t0 == SRH_PRIM_DISK || t0 == SRH_PRIM_TRIANGLE) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) v[i] = R[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) v[i] = 0.0;
+      }
+      m = clampi(F.seg[0].mat[li], 0, F.nmat - 1);
+      return;
+    }
     int first = F.seg[0].first;
     const double* base = F.seg[0].rec64;
     const int32_t* mat = F.seg[0].mat;
