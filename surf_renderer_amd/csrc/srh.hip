@@ -836,13 +836,18 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     // one wave per tile while that still gives every SIMD several waves; four waves per tile for small frames / slabs
     const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4) ? params->waves_per_tile == 4
                                                                                    : binned_waves_per_tile(F) == 4;
+    const dim3 g4(groups * 4), b4(256), g1(groups * (4 / kWavesPerGroup1)), b1(64 * kWavesPerGroup1);
+    const bool one = F.nseg == 1;                   // one object batch: the instantiation without per-batch generality
+#define SRH_LAUNCH_BINNED(TCH_, WPT_, ONE_, G_, B_) \
+    hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, ONE_>), G_, B_, 0, st, F, image, depth, nearest)
     if (F.shading) {
-      if (split) hipLaunchKernelGGL((k_render_binned<true, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
-      else hipLaunchKernelGGL((k_render_binned<true, 1>), dim3(groups * (4 / kWavesPerGroup1)), dim3(64 * kWavesPerGroup1), 0, st, F, image, depth, nearest);
+      if (split) { if (one) SRH_LAUNCH_BINNED(true, 4, true, g4, b4); else SRH_LAUNCH_BINNED(true, 4, false, g4, b4); }
+      else { if (one) SRH_LAUNCH_BINNED(true, 1, true, g1, b1); else SRH_LAUNCH_BINNED(true, 1, false, g1, b1); }
     } else {
-      if (split) hipLaunchKernelGGL((k_render_binned<false, 4>), dim3(groups * 4), dim3(256), 0, st, F, image, depth, nearest);
-      else hipLaunchKernelGGL((k_render_binned<false, 1>), dim3(groups * (4 / kWavesPerGroup1)), dim3(64 * kWavesPerGroup1), 0, st, F, image, depth, nearest);
+      if (split) { if (one) SRH_LAUNCH_BINNED(false, 4, true, g4, b4); else SRH_LAUNCH_BINNED(false, 4, false, g4, b4); }
+      else { if (one) SRH_LAUNCH_BINNED(false, 1, true, g1, b1); else SRH_LAUNCH_BINNED(false, 1, false, g1, b1); }
     }
+#undef SRH_LAUNCH_BINNED
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     if (F.ortho) hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, image, depth, nearest);

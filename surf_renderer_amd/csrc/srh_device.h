@@ -324,7 +324,7 @@ struct ShadeHint {
   double n[3];        // its unit normal (planar types; unused for spheres)
 };
 
-template <bool TCH>
+template <bool TCH, bool ONE = false>
 __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
                                               float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr,
                                               const double* origin = nullptr, uint64_t vis = ~0ull) {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
   const float* seg_pos = F.seg[0].pos;
   const double* seg_rec64 = F.seg[0].rec64;
   const int32_t* seg_mat = F.seg[0].mat;
-  if (F.nseg > 1) {
+  if (!ONE && F.nseg > 1) {
 #pragma unroll
     for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
       if (i < F.nseg && win >= F.seg[i].first) {
