@@ -837,15 +837,20 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4) ? params->waves_per_tile == 4
                                                                                    : binned_waves_per_tile(F) == 4;
     const dim3 g4(groups * 4), b4(256), g1(groups * (4 / kWavesPerGroup1)), b1(64 * kWavesPerGroup1);
-    const bool one = F.nseg == 1;                   // one object batch: the instantiation without per-batch generality
-#define SRH_LAUNCH_BINNED(TCH_, WPT_, ONE_, G_, B_) \
-    hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, ONE_>), G_, B_, 0, st, F, image, depth, nearest)
+    // one object batch of a known type: the instantiation without per-batch generality and without the other types' code
+    const int batch = F.nseg == 1 ? F.seg[0].type : -1;
+#define SRH_LAUNCH_BINNED(TCH_, WPT_, G_, B_)                                                                          \
+    switch (batch) {                                                                                                   \
+      case SRH_PRIM_DISK: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_DISK>), G_, B_, 0, st, F, image, depth, nearest); break;       \
+      case SRH_PRIM_PLANE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_PLANE>), G_, B_, 0, st, F, image, depth, nearest); break;     \
+      case SRH_PRIM_SPHERE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_SPHERE>), G_, B_, 0, st, F, image, depth, nearest); break;   \
+      case SRH_PRIM_TRIANGLE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_TRIANGLE>), G_, B_, 0, st, F, image, depth, nearest); break; \
+      default: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, -1>), G_, B_, 0, st, F, image, depth, nearest); break;  \
+    }
     if (F.shading) {
-      if (split) { if (one) SRH_LAUNCH_BINNED(true, 4, true, g4, b4); else SRH_LAUNCH_BINNED(true, 4, false, g4, b4); }
-      else { if (one) SRH_LAUNCH_BINNED(true, 1, true, g1, b1); else SRH_LAUNCH_BINNED(true, 1, false, g1, b1); }
+      if (split) { SRH_LAUNCH_BINNED(true, 4, g4, b4) } else { SRH_LAUNCH_BINNED(true, 1, g1, b1) }
     } else {
-      if (split) { if (one) SRH_LAUNCH_BINNED(false, 4, true, g4, b4); else SRH_LAUNCH_BINNED(false, 4, false, g4, b4); }
-      else { if (one) SRH_LAUNCH_BINNED(false, 1, true, g1, b1); else SRH_LAUNCH_BINNED(false, 1, false, g1, b1); }
+      if (split) { SRH_LAUNCH_BINNED(false, 4, g4, b4) } else { SRH_LAUNCH_BINNED(false, 1, g1, b1) }
     }
 #undef SRH_LAUNCH_BINNED
   } else if (mode == SRH_MODE_EXACT) {

@@ -267,12 +267,12 @@ __device__ __forceinline__ float float_above(double t) { return (float)t * 1.000
 
 // ONE (here and below): the kernel instantiation for scenes with one object batch -- per-batch loops and per-lane batch
 // selections fold away at compile time
-template <bool TCH, bool ONE = false>
+template <bool TCH, int BATCH = -1>
 __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, const double d[3], double& best,
                                                int& besti) {
-  if (ONE || F.nseg == 1) {
+  if ((BATCH >= 0) || F.nseg == 1) {
     // one object batch (the common scene): type and base are wave-uniform, the intersection is chosen by a scalar branch
-    const int type = F.seg[0].type;
+    const int type = BATCH >= 0 ? BATCH : F.seg[0].type;
     const double* R = F.seg[0].rec64 + (size_t)(gidx - F.seg[0].first) * kRec64Stride[type];
     resolve_lex(F, hit_any64(type, R, F.o, d, TCH), gidx, best, besti);
     return;
@@ -290,7 +290,7 @@ __device__ __forceinline__ void confirm_global(const FrameDev& F, int gidx, cons
 // The fp64 record of a pixel's front candidate, fetched ahead of its use (see the finish rounds): up to eight doubles
 // in registers (all of a disc, plane or sphere record; normal and plane offset of a triangle), plus the material
 // index for the fragment stage.  g < 0 (no front candidate) fetches primitive 0, and nobody looks at the result.
-template <bool TCH, bool ONE = false>
+template <bool TCH, int BATCH = -1>
 struct FrontRecord {
   int g, type, m;
   const double* R;
@@ -298,8 +298,8 @@ struct FrontRecord {
   __device__ __forceinline__ void fetch(const FrameDev& F, int gidx) {
     g = gidx;
     const int gs = max(gidx, 0);
-    if (ONE || F.nseg == 1) {               // one batch: type, stride and bases are wave-uniform
-      const int t0 = F.seg[0].type;
+    if ((BATCH >= 0) || F.nseg == 1) {               // one batch: type, stride and bases are wave-uniform
+      const int t0 = BATCH >= 0 ? BATCH : F.seg[0].type;
       type = t0;
       const int li = gs - F.seg[0].first;
       R = F.seg[0].rec64 + (size_t)li * kRec64Stride[t0];
@@ -319,7 +319,7 @@ struct FrontRecord {
     const double* base = F.seg[0].rec64;
     const int32_t* mat = F.seg[0].mat;
     type = F.seg[0].type;
-    if (!ONE && F.nseg > 1) {               // one batch: everything above is already right (and wave-uniform)
+    if (!(BATCH >= 0) && F.nseg > 1) {               // one batch: everything above is already right (and wave-uniform)
       const int s = segment_of(F, gs);
 #pragma unroll
       for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
@@ -341,8 +341,8 @@ struct FrontRecord {
     m = clampi(mat[li], 0, F.nmat - 1);
   }
   __device__ __forceinline__ double hit(const FrameDev& F, const double d[3]) const {
-    if (ONE || F.nseg == 1) {               // wave-uniform type: a scalar branch picks the intersection
-      switch (F.seg[0].type) {
+    if ((BATCH >= 0) || F.nseg == 1) {               // wave-uniform type: a scalar branch picks the intersection
+      switch (BATCH >= 0 ? BATCH : F.seg[0].type) {
         case SRH_PRIM_DISK: return hit_disk64(v, d);
         case SRH_PRIM_PLANE: return hit_plane64(v, d);
         case SRH_PRIM_SPHERE: return TCH ? hit_sphere64_tch(v, d) : hit_sphere64(v, d);
@@ -576,7 +576,7 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
 // entry is wave-uniform, so the records arrive by scalar loads and the fp64 confirmation runs for all lanes that
 // need it at once.  Used when several pixels of a round are undecided (overlapping coplanar splats, clouds of
 // primitives without a usable depth estimate); a lone undecided pixel is cheaper on the wave-serial walk below.
-template <int TYPE, bool PRETEST, bool TCH, bool ONE = false>
+template <int TYPE, bool PRETEST, bool TCH, int BATCH = -1>
 __device__ __forceinline__ void resweep_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
                                              uint32_t n, bool open, const f32x2 (&cf)[2], float rf,
                                              const f32x2 (&rlen)[2], const double d[3], float& bound, double& best,
@@ -608,7 +608,7 @@ struct SlowPixel {
   int g1, g2;         // already confirmed
 };
 
-template <int TYPE, bool PRETEST, bool TCH, bool ONE = false>
+template <int TYPE, bool PRETEST, bool TCH, int BATCH = -1>
 __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, const uint32_t* __restrict__ list,
                                           uint32_t n, int lane, const SlowPixel& P, const double d[3],
                                           double& best, int& besti) {
@@ -621,7 +621,7 @@ __device__ __forceinline__ void slow_list(const FrameDev& F, const SegDev& S, co
     pair_bounds<TYPE, PRETEST>(R, P.cf, P.rf, P.rlen, sel, inv);
     const float iv = inv[0][0];
     if (sel[0] && iv > 0.0f && iv >= reach_of(P.bound) && g != P.g1 && g != P.g2)
-      confirm_global<TCH, ONE>(F, g, d, best, besti);
+      confirm_global<TCH, BATCH>(F, g, d, best, besti);
   }
 }
 
@@ -658,17 +658,17 @@ struct TileLists {
   }
 };
 
-template <bool PRETEST, int WPT, bool ONE = false>
+template <bool PRETEST, int WPT, int BATCH = -1>
 __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part, int lane) {
   const TileLists L{F, tile};
   uint32_t ord0 = 0;
-  for (int s = 0; s < (ONE ? 1 : F.nseg); ++s) {
+  for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) {
     const SegDev& S = F.seg[s];
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
-      switch (S.type) {
+      switch (BATCH >= 0 ? BATCH : S.type) {
         case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
         case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
         case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
@@ -680,16 +680,16 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
 }
 
 // Global primitive index of the entry with ordinal `ord` (per lane) in the tile's lists; -1 if out of range.
-template <bool ONE = false>
+template <int BATCH = -1>
 __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, uint32_t ord) {
   const TileLists L{F, tile};
-  if ((ONE || F.nseg == 1) && L.count(0, 0) == 0) {          // one batch, nothing frame-wide: the ordinal is the bin-list position
+  if (((BATCH >= 0) || F.nseg == 1) && L.count(0, 0) == 0) {          // one batch, nothing frame-wide: the ordinal is the bin-list position
     const uint32_t n = L.count(0, 1);
     return ord < n ? (int)L.list(0, 1)[min(ord, n - 1)] : -1;
   }
   int g = -1;
   bool done = false;
-  for (int s = 0; s < (ONE ? 1 : F.nseg); ++s) {
+  for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) {
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t n = L.count(s, pass);
@@ -702,7 +702,7 @@ __device__ __forceinline__ int ordinal_to_global(const FrameDev& F, int tile, ui
 
 // Resolve the pixel of lane `src` on the slow path with the whole wave; returns the merged (t, index) minimum of
 // everything confirmed here (index 0x7fffffff = nothing), valid in every lane.
-template <bool PRETEST, bool TCH, bool ONE = false>
+template <bool PRETEST, bool TCH, int BATCH = -1>
 __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane, int src, float cf, float rf,
                                            float len, float bound, int g1, int g2, const double d[3],
                                            double& out_t, int& out_i) {
@@ -718,17 +718,17 @@ __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane
   double best = __builtin_inf();
   int besti = 0x7fffffff;
   const TileLists L{F, tile};
-  for (int s = 0; s < (ONE ? 1 : F.nseg); ++s) {
+  for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) {
     const SegDev& S = F.seg[s];
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
-      switch (S.type) {
-        case SRH_PRIM_DISK: slow_list<SRH_PRIM_DISK, PRETEST, TCH, ONE>(F, S, list, n, lane, P, ds, best, besti); break;
-        case SRH_PRIM_PLANE: slow_list<SRH_PRIM_PLANE, PRETEST, TCH, ONE>(F, S, list, n, lane, P, ds, best, besti); break;
-        case SRH_PRIM_SPHERE: slow_list<SRH_PRIM_SPHERE, PRETEST, TCH, ONE>(F, S, list, n, lane, P, ds, best, besti); break;
-        default: slow_list<SRH_PRIM_TRIANGLE, PRETEST, TCH, ONE>(F, S, list, n, lane, P, ds, best, besti); break;
+      switch (BATCH >= 0 ? BATCH : S.type) {
+        case SRH_PRIM_DISK: slow_list<SRH_PRIM_DISK, PRETEST, TCH, BATCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_PLANE: slow_list<SRH_PRIM_PLANE, PRETEST, TCH, BATCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        case SRH_PRIM_SPHERE: slow_list<SRH_PRIM_SPHERE, PRETEST, TCH, BATCH>(F, S, list, n, lane, P, ds, best, besti); break;
+        default: slow_list<SRH_PRIM_TRIANGLE, PRETEST, TCH, BATCH>(F, S, list, n, lane, P, ds, best, besti); break;
       }
     }
   }
@@ -742,24 +742,24 @@ __device__ __forceinline__ void slow_pixel(const FrameDev& F, int tile, int lane
   out_i = besti;
 }
 
-template <bool PRETEST, bool TCH, bool ONE = false>
+template <bool PRETEST, bool TCH, int BATCH = -1>
 __device__ __forceinline__ void resweep_tile(const FrameDev& F, int tile, bool open, float cf, float rf, float len,
                                              const double d[3], float& bound, double& best, int& besti) {
   const f32x2 cfq[2] = {f32x2{cf, cf}, f32x2{cf, cf}};
   const float rl = __builtin_amdgcn_rcpf(len);
   const f32x2 rlq[2] = {f32x2{rl, rl}, f32x2{rl, rl}};
   const TileLists L{F, tile};
-  for (int s = 0; s < (ONE ? 1 : F.nseg); ++s) {
+  for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) {
     const SegDev& S = F.seg[s];
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
-      switch (S.type) {
-        case SRH_PRIM_DISK: resweep_list<SRH_PRIM_DISK, PRETEST, TCH, ONE>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
-        case SRH_PRIM_PLANE: resweep_list<SRH_PRIM_PLANE, PRETEST, TCH, ONE>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
-        case SRH_PRIM_SPHERE: resweep_list<SRH_PRIM_SPHERE, PRETEST, TCH, ONE>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
-        default: resweep_list<SRH_PRIM_TRIANGLE, PRETEST, TCH, ONE>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+      switch (BATCH >= 0 ? BATCH : S.type) {
+        case SRH_PRIM_DISK: resweep_list<SRH_PRIM_DISK, PRETEST, TCH, BATCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        case SRH_PRIM_PLANE: resweep_list<SRH_PRIM_PLANE, PRETEST, TCH, BATCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        case SRH_PRIM_SPHERE: resweep_list<SRH_PRIM_SPHERE, PRETEST, TCH, BATCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
+        default: resweep_list<SRH_PRIM_TRIANGLE, PRETEST, TCH, BATCH>(F, S, list, n, open, cfq, rf, rlq, d, bound, best, besti); break;
       }
     }
   }
@@ -880,7 +880,7 @@ __device__ __forceinline__ void binned_tile_of(const FrameDev& F, int wave, int&
     ty = (int)(ry * kRegionH + within / kRegionW);
 }
 
-template <bool TCH, int WPT, bool ONE = false>
+template <bool TCH, int WPT, int BATCH = -1>
 __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ F, float* __restrict__ image,
                                                    float* __restrict__ depth, int32_t* __restrict__ nearest) {
   constexpr int kWaves = WPT == 1 ? kWavesPerGroup1 : 4;   // waves of the workgroup
@@ -911,7 +911,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   uint32_t listed = 0;
   {
     const TileLists L{F, tile};
-    for (int s = 0; s < (ONE ? 1 : F.nseg); ++s) listed |= L.count(s, 0) | L.count(s, 1);
+    for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) listed |= L.count(s, 0) | L.count(s, 1);
   }
   if (listed) {
     const int r = min(r_raw, F.row1 - 1);
@@ -949,8 +949,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps
-    if (pretest) sweep_tile<true, WPT, ONE>(F, tile, Q, part, lane);
-    else sweep_tile<false, WPT, ONE>(F, tile, Q, part, lane);
+    if (pretest) sweep_tile<true, WPT, BATCH>(F, tile, Q, part, lane);
+    else sweep_tile<false, WPT, BATCH>(F, tile, Q, part, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Parked p;
@@ -989,7 +989,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       front[wave][j][lane] =
-          (((has >> j) & 1u) && !key_saturated(Q.k1[j])) ? ordinal_to_global<ONE>(F, tile, key_ordinal(Q.k1[j])) : -1;
+          (((has >> j) & 1u) && !key_saturated(Q.k1[j])) ? ordinal_to_global<BATCH>(F, tile, key_ordinal(Q.k1[j])) : -1;
     }
   }
 
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       const int gfront = front[wave][j][src];
       // The front candidate's record and material index are requested before the ray is set up, so that their
       // latency overlaps that arithmetic; nearly always this candidate is also the winner that gets shaded.
-      FrontRecord<TCH, ONE> fr;
+      FrontRecord<TCH, BATCH> fr;
       fr.fetch(F, gfront);
       double d[3];
       const float len = (float)pixel_ray(F, c, r, d);
@@ -1075,11 +1075,11 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
             if (key_saturated(key)) {
               saturated = true;
             } else {
-              const int g = (q == 0) ? gfront : ordinal_to_global<ONE>(F, tile, key_ordinal(key));
+              const int g = (q == 0) ? gfront : ordinal_to_global<BATCH>(F, tile, key_ordinal(key));
               if (q == 0) g1 = g;
               if (q == 1) g2 = g;
               if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
-              else confirm_global<TCH, ONE>(F, g, d, best, besti);
+              else confirm_global<TCH, BATCH>(F, g, d, best, besti);
               bound = float_above(best);
               reach = reach_of(bound);                  // bound = inf (a miss) gives 0 again
             }
@@ -1094,8 +1094,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       unsigned long long todo = __builtin_amdgcn_ballot_w64(slow);
       if (__popcll(todo) > kSerialSlowMax) {      // several undecided pixels: all of them at once, lane-parallel
         if (slow) { best = __builtin_inf(); besti = 0x7fffffff; bound = __builtin_inff(); }   // confirm everything that passes
-        if (pretest) resweep_tile<true, TCH, ONE>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
-        else resweep_tile<false, TCH, ONE>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
+        if (pretest) resweep_tile<true, TCH, BATCH>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
+        else resweep_tile<false, TCH, BATCH>(F, tile, slow, (float)c, (float)r, len, d, bound, best, besti);
         todo = 0;
       }
       while (todo) {                          // wave-uniform loop over the lanes whose pixel needs the slow path
@@ -1103,8 +1103,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         todo &= todo - 1;
         double st;
         int si;
-        if (pretest) slow_pixel<true, TCH, ONE>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
-        else slow_pixel<false, TCH, ONE>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        if (pretest) slow_pixel<true, TCH, BATCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
+        else slow_pixel<false, TCH, BATCH>(F, tile, lane, sl, (float)c, (float)r, len, bound, g1, g2, d, st, si);
         if (lane == sl && si != 0x7fffffff && (st < best || (st == best && (si < besti || besti == 0x7fffffff)))) {
           best = st;
           besti = si;
@@ -1118,7 +1118,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         rgb[0] = rgb[1] = rgb[2] = (float)d[0] + __int_as_float(p.k1);
 #else
         const ShadeHint hint = fr.hint();
-        shade_pixel_t<TCH, ONE>(F, d, best, besti, rgb, want_aux ? aux : nullptr, &hint);
+        shade_pixel_t<TCH, BATCH>(F, d, best, besti, rgb, want_aux ? aux : nullptr, &hint);
 #endif
         const size_t row = (size_t)(r - F.row0);
         float* px = image + row * F.img_stride + 3 * (size_t)c;
@@ -1135,10 +1135,10 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   }
 }
 
-template <bool TCH, int WPT, bool ONE = false>
+template <bool TCH, int WPT, int BATCH = -1>
 __global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(
     FrameDev F, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
-  render_binned_body<TCH, WPT, ONE>(F, image, depth, nearest);
+  render_binned_body<TCH, WPT, BATCH>(F, image, depth, nearest);
 }
 
 // ---- many views per launch (srh_render_views): blockIdx.y selects the view, whose FrameDev lives in device memory;

@@ -324,7 +324,7 @@ struct ShadeHint {
   double n[3];        // its unit normal (planar types; unused for spheres)
 };
 
-template <bool TCH, bool ONE = false>
+template <bool TCH, int BATCH = -1>
 __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[3], double z, int win,
                                               float rgb[3], float aux[6] = nullptr, const ShadeHint* hint = nullptr,
                                               const double* origin = nullptr, uint64_t vis = ~0ull) {
@@ -338,11 +338,11 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     return;
   }
   // the winner's batch: with one batch in the scene (wave-uniform test) nothing has to be selected per lane
-  int seg_type = F.seg[0].type, seg_first = F.seg[0].first;
+  int seg_type = BATCH >= 0 ? BATCH : F.seg[0].type, seg_first = F.seg[0].first;
   const float* seg_pos = F.seg[0].pos;
   const double* seg_rec64 = F.seg[0].rec64;
   const int32_t* seg_mat = F.seg[0].mat;
-  if (!ONE && F.nseg > 1) {
+  if (BATCH < 0 && F.nseg > 1) {
 #pragma unroll
     for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
       if (i < F.nseg && win >= F.seg[i].first) {
