@@ -1135,8 +1135,21 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   }
 }
 
+// Waves per SIMD the register allocator aims at.  The all-types kernel needs 128 VGPRs (4 waves); the one-batch
+// instantiations need 87-116: disc / sphere fit 5 waves with 0-4 registers spilled, plane 6 with none, the triangle
+// kernel would spill 10 at 5 waves and is slower there (config 4: 0.0553 -> 0.0562 ms), so it stays at 4.  With 5
+// waves per SIMD config 5 goes from 0.0927 to 0.0852 ms per frame (stand-alone kernel 90.5 -> 88.0 us): the extra
+// slot is what the other frames' binning waves need beside the render waves.
+#ifndef SRH_TYPED_WAVES
+#define SRH_TYPED_WAVES 0
+#endif
+constexpr int typed_waves(bool tch, int batch) {      // the Phong fragment stage needs more registers: 4 waves as before
+  return (batch < 0 || tch) ? 4 : SRH_TYPED_WAVES ? SRH_TYPED_WAVES
+       : batch == SRH_PRIM_TRIANGLE ? 4 : batch == SRH_PRIM_PLANE ? 6 : 5;
+}
 template <bool TCH, int WPT, int BATCH = -1>
-__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned(
+__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256)
+__attribute__((amdgpu_waves_per_eu(typed_waves(TCH, BATCH)))) void k_render_binned(
     FrameDev F, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
   render_binned_body<TCH, WPT, BATCH>(F, image, depth, nearest);
 }
