@@ -40,10 +40,12 @@ VALU_PEAK_GINSTR_S = 614.4
 PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 
 
-# --schedule auto: the stage schedule is chosen when one frame's render kernel takes at least this many times as long as
-# its binning kernels (measured: config 5, ratio 2.6, stages = frames in steady state and 2 % better over 20 steps; half
-# a frame, ratio 2.0, stages 35 % WORSE -- the prioritised render streams starve the one binning stream)
-STAGES_MIN_RATIO = 2.3
+# --schedule auto: the stage schedule is chosen for whole frames whose render kernel takes at least this many times as
+# long as their clear + binning (measured at config 5, ratio 2.15 with the typed render kernel: stages 0.0863 / frames
+# 0.0851 ms in steady state, 0.0889 / 0.0913 over a 20-step timed region; row slabs -- a rank's half frame, ratio 2.1 --
+# were 35 % WORSE in the stage schedule, whose prioritised render streams starve the one binning stream, and stay with
+# whole frames per stream)
+STAGES_MIN_RATIO = 2.0
 
 
 def load_pmc():
@@ -79,7 +81,7 @@ def parse():
                          "one stream for every frame's binning kernels, --render-streams for the render kernels (same "
                          "steady state, 2 %% faster over a 20-step timed region: the streams do not start in lockstep); "
                          "auto = stages when the frames are binned, graphs are on, at least three frames are in flight and "
-                         "the render kernel of one frame takes at least twice as long as its binning (timed once), "
+                         "the render kernel of a whole frame takes at least twice as long as its binning (timed once), "
                          "else frames")
     ap.add_argument("--render-streams", type=int, default=2, help="--schedule stages: streams the render kernels alternate over")
     ap.add_argument("--bin-priority", action="store_true", help="--schedule stages: the binning stream gets the higher priority")
@@ -604,7 +606,8 @@ def main():
             # long half (config 5: 100 us against 40), wrong for small frames and row slabs, where three binning chains
             # side by side are what hides their latency.  Decided by timing one frame's halves.
             schedule = "frames"
-            if args.mode in ("auto", "binned") and graph_state["on"] and rotate == 1 and n_str >= 3:
+            if args.mode in ("auto", "binned") and graph_state["on"] and rotate == 1 and n_str >= 3 and \
+                    (r0, r1) == (0, H):
                 try:                                   # the library refuses split frames that are not binned
                     bin_ms, render_ms = halves_ms()
                     halves = {"bin_ms": round(bin_ms, 4), "render_ms": round(render_ms, 4)}
