@@ -1016,12 +1016,23 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   // all views share the GPU, so the batch as a whole decides the launch shape
   const bool split = (params->waves_per_tile == 1 || params->waves_per_tile == 4)
                          ? params->waves_per_tile == 4 : (size_t)F0.ntiles * V < (size_t)SRH_SPLIT_TILES;
-  if (F0.shading) {
-    if (split) hipLaunchKernelGGL((k_render_binned_views<true, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<true, 1>), dim3(groups * (4 / kWavesPerGroup1), V), dim3(64 * kWavesPerGroup1), 0, st, base, images, depths, nearests);
-  } else {
-    if (split) hipLaunchKernelGGL((k_render_binned_views<false, 4>), dim3(groups * 4, V), dim3(256), 0, st, base, images, depths, nearests);
-    else hipLaunchKernelGGL((k_render_binned_views<false, 1>), dim3(groups * (4 / kWavesPerGroup1), V), dim3(64 * kWavesPerGroup1), 0, st, base, images, depths, nearests);
+  {
+    const dim3 g4(groups * 4, V), b4(256), g1(groups * (4 / kWavesPerGroup1), V), b1(64 * kWavesPerGroup1);
+    const int batch = F0.nseg == 1 ? F0.seg[0].type : -1;        // as in srh_render_fwd: the typed instantiation
+#define SRH_LAUNCH_VIEWS(TCH_, WPT_, G_, B_)                                                                            \
+    switch (batch) {                                                                                                   \
+      case SRH_PRIM_DISK: hipLaunchKernelGGL((k_render_binned_views<TCH_, WPT_, SRH_PRIM_DISK>), G_, B_, 0, st, base, images, depths, nearests); break;       \
+      case SRH_PRIM_PLANE: hipLaunchKernelGGL((k_render_binned_views<TCH_, WPT_, SRH_PRIM_PLANE>), G_, B_, 0, st, base, images, depths, nearests); break;     \
+      case SRH_PRIM_SPHERE: hipLaunchKernelGGL((k_render_binned_views<TCH_, WPT_, SRH_PRIM_SPHERE>), G_, B_, 0, st, base, images, depths, nearests); break;   \
+      case SRH_PRIM_TRIANGLE: hipLaunchKernelGGL((k_render_binned_views<TCH_, WPT_, SRH_PRIM_TRIANGLE>), G_, B_, 0, st, base, images, depths, nearests); break; \
+      default: hipLaunchKernelGGL((k_render_binned_views<TCH_, WPT_, -1>), G_, B_, 0, st, base, images, depths, nearests); break;  \
+    }
+    if (F0.shading) {
+      if (split) { SRH_LAUNCH_VIEWS(true, 4, g4, b4) } else { SRH_LAUNCH_VIEWS(true, 1, g1, b1) }
+    } else {
+      if (split) { SRH_LAUNCH_VIEWS(false, 4, g4, b4) } else { SRH_LAUNCH_VIEWS(false, 1, g1, b1) }
+    }
+#undef SRH_LAUNCH_VIEWS
   }
   // the slot is consumed only now: a call that failed validation above leaves the ring as it was
   const hipError_t er = hipEventRecord(ring.done[slot], st);

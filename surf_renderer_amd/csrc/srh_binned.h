@@ -1171,13 +1171,14 @@ constexpr int kMaxViewsPerCall = 256;
 constexpr int kViewRing = 4;                       // batches in flight before the host has to wait
 __constant__ FrameDev g_view_frames[kViewRing * kMaxViewsPerCall];
 
-template <bool TCH, int WPT>
-__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256) __attribute__((amdgpu_waves_per_eu(4))) void k_render_binned_views(
+template <bool TCH, int WPT, int BATCH = -1>
+__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256)
+__attribute__((amdgpu_waves_per_eu(typed_waves(TCH, BATCH)))) void k_render_binned_views(
     int base, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
   const FrameDev& F = g_view_frames[base + blockIdx.y];
   const size_t rows = (size_t)(F.row1 - F.row0), v = blockIdx.y;
-  render_binned_body<TCH, WPT>(F, image + v * rows * F.img_stride, depth + v * rows * F.depth_stride,
-                               nearest ? nearest + v * rows * F.near_stride : nullptr);
+  render_binned_body<TCH, WPT, BATCH>(F, image + v * rows * F.img_stride, depth + v * rows * F.depth_stride,
+                                      nearest ? nearest + v * rows * F.near_stride : nullptr);
 }
 
 }  // namespace srh
