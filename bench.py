@@ -41,11 +41,12 @@ PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 
 
 # --schedule auto: the stage schedule is chosen for whole frames whose render kernel takes at least this many times as
-# long as their clear + binning (measured at config 5, ratio 2.15 with the typed render kernel: stages 0.0863 / frames
-# 0.0851 ms in steady state, 0.0889 / 0.0913 over a 20-step timed region; row slabs -- a rank's half frame, ratio 2.1 --
-# were 35 % WORSE in the stage schedule, whose prioritised render streams starve the one binning stream, and stay with
-# whole frames per stream)
-STAGES_MIN_RATIO = 2.0
+# long as their clear + binning.  Measured at config 5: with the 105 us render kernel (ratio 2.55) stages = frames in
+# steady state and 2 % better over a 20-step timed region; with the typed 88 us kernel (ratio 2.15-2.2) stages is 1-7 %
+# WORSE in steady state (0.0863-0.092 against 0.0851 ms, box to box) and 0-3 % better over 20 steps -- so it is no
+# longer taken there.  Row slabs (a rank's half frame, ratio 2.1) were 35 % worse in the stage schedule, whose
+# prioritised render streams starve the one binning stream.
+STAGES_MIN_RATIO = 2.3
 
 
 def load_pmc():
