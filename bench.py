@@ -75,8 +75,8 @@ def parse():
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
-                         "overlap the render kernel of another.  Default 3 (measured: 1 -> 5.3k, 2 -> 7.7k, 3 -> 8.1k, "
-                         "4 -> 7.1k frames/s on one MI355X)")
+                         "overlap the render kernel of another.  Default 3 (measured: 1 -> 7.5k, 2 -> 11.6k, 3 -> 11.8k, "
+                         "4 -> 10.3k frames/s on one MI355X)")
     ap.add_argument("--schedule", default="auto", choices=["auto", "frames", "stages", "render-only", "bin-only"],
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
                          "one stream for every frame's binning kernels, --render-streams for the render kernels (same "
