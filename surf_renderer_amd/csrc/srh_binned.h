@@ -65,11 +65,12 @@ __device__ __forceinline__ int rec32_stride(int type) {
        : type == SRH_PRIM_SPHERE ? kRec32Stride[2] : kRec32Stride[3];
 }
 
-// Workgroup size of the per-primitive kernels (prep, count, fill): ONE wave.  They run beside other frames' render
+// Workgroup size of the per-primitive kernels (prep, count): ONE wave.  They run beside other frames' render
 // kernels, whose single-wave workgroups refill every slot the moment it is free; a four-wave workgroup would wait for
-// four free slots on one CU and starve.
+// four free slots on one CU and starve.  (Measured together with SRH_GROUP_WAVES below: 256/4 0.0850 ms per frame at
+// config 5, 256/1 0.0948-0.0980, 64/1 0.0816.)
 #ifndef SRH_BIN_BLOCK
-#define SRH_BIN_BLOCK 256
+#define SRH_BIN_BLOCK 64
 #endif
 constexpr int kBinBlock = SRH_BIN_BLOCK;
 // Place the primitive from k_prep itself (a thread per primitive walks its box right after it built the record): no
@@ -803,9 +804,10 @@ __host__ inline unsigned binned_grid(const FrameDev& F) {
 // (10th / 50th / 90th percentile of a wave's life at config 5: 3 / 29 / 50 us): with four waves per workgroup a
 // finished wave's slot stays empty until the workgroup's slowest wave is done and four slots are free together --
 // measured 3.0 resident waves per SIMD of the 4 the registers allow.  One wave per workgroup: a slot is refilled
-// as soon as its wave ends.
+// as soon as its wave ends.  That only pays when the per-primitive kernels of the frames in flight use one-wave
+// workgroups too (SRH_BIN_BLOCK above), or they starve behind the render waves.
 #ifndef SRH_GROUP_WAVES
-#define SRH_GROUP_WAVES 4
+#define SRH_GROUP_WAVES 1
 #endif
 constexpr int kWavesPerGroup1 = SRH_GROUP_WAVES;   // 1 or 4
 static_assert(kWavesPerGroup1 == 1 || kWavesPerGroup1 == 4, "SRH_GROUP_WAVES");
