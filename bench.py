@@ -43,7 +43,7 @@ PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 # --schedule auto: the stage schedule is chosen for whole frames whose render kernel takes at least this many times as
 # long as their clear + binning.  Measured at config 5: with the 105 us render kernel (ratio 2.55) stages = frames in
 # steady state and 2 % better over a 20-step timed region; with the typed 88 us kernel (ratio 2.15-2.2) stages is 1-7 %
-# WORSE in steady state (0.0863-0.092 against 0.0851 ms, box to box) and 0-3 % better over 20 steps -- so it is no
+# WORSE in steady state (0.0863-0.092 against 0.0851 ms, box to box; measured before the one-wave workgroups) and 0-3 % better over 20 steps -- so it is no
 # longer taken there.  Row slabs (a rank's half frame, ratio 2.1) were 35 % worse in the stage schedule, whose
 # prioritised render streams starve the one binning stream.
 STAGES_MIN_RATIO = 2.3
@@ -75,8 +75,8 @@ def parse():
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight: each has its own stream and scratch, so the binning kernels of one frame "
-                         "overlap the render kernel of another.  Default 3 (measured: 1 -> 7.5k, 2 -> 11.6k, 3 -> 11.8k, "
-                         "4 -> 10.3k frames/s on one MI355X)")
+                         "overlap the render kernel of another.  Default 3 (measured: 1 -> 7.7k, 2 -> 11.9k, 3 -> 12.2k, "
+                         "4 -> 10.7k, 5 -> 12.1k, 6 -> 12.3k frames/s on one MI355X)")
     ap.add_argument("--schedule", default="auto", choices=["auto", "frames", "stages", "render-only", "bin-only"],
                     help="single process: 'frames' = each frame whole on its own stream (--inflight of them); 'stages' = "
                          "one stream for every frame's binning kernels, --render-streams for the render kernels (same "
