@@ -229,6 +229,18 @@ def literal_root0_leg(args, buf, cam, device, rank, world, W, H):
             "check": "rank 0's assembled frames equal an eager full-frame render bit for bit" if args.check else "off"}
 
 
+def ranks_agree_failed(bad, rank, device, what):
+    """True on every rank when the check failed on any rank (one all-reduce; every rank must call it).
+    SRH_BENCH_INJECT_CHECK_FAIL=<rank> makes that rank report a failure (rehearsal of the fallback)."""
+    if os.environ.get("SRH_BENCH_INJECT_CHECK_FAIL") == str(rank):
+        bad = True
+    flag = torch.tensor([0.0 if bad else 1.0], device=device)
+    if bad:
+        print(f"[bench] rank {rank}: check FAILED: {what}", file=sys.stderr)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return float(flag.item()) < 1.0
+
+
 def measure_exchange(device, rank, world, W, H, reps=10):
     """Measured rate of the two collections on this node's links, nothing else running: bytes that cross the links per
     rank divided by the wall time of the collective alone (max over ranks).  all-to-all of one batch of `world` frames
@@ -741,6 +753,10 @@ def main():
         elapsed = float(t.item())
 
     check_note = None
+    # A multi-rank schedule (owner-weighted or batched all-to-all) whose frames fail the bit-for-bit check on ANY rank does
+    # not end the run: every rank learns of it (one all-reduce), the headline then comes from the metric's literal form
+    # below -- equal slabs, one gather per frame to rank 0, checked the same way -- and the line says so.
+    collection_failed = False
     if args.check and owner:
         ref = torch.empty((H, 4 * W), dtype=torch.float32, device=device)
         renderer.render_buffers(buf, cam, rows=(0, H), mode=args.mode, out=(*views(ref), None))
@@ -748,11 +764,11 @@ def main():
         rendered = warm_steps + args.steps
         got = [recv[b] for b in range(n_bat)
                if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
-        for t in got:                                  # the whole frame assembled on this rank, every rank's rows
-            if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
-                raise SystemExit(f"[bench] rank {rank}: an assembled frame differs from the eager full-frame render")
+        # the whole frame assembled on this rank, every rank's rows
+        bad = any(not torch.equal(t.view(torch.int32), ref.view(torch.int32)) for t in got)
+        collection_failed = ranks_agree_failed(bad, rank, device, "an assembled frame differs from the eager full-frame render")
         check_note = f"{len(got)} assembled frame(s) equal the eager full-frame render bit for bit"
-        if rank == 0:
+        if rank == 0 and not collection_failed:
             print(f"[bench] check ok: {check_note}", file=sys.stderr)
     elif args.check and pipe is not None:
         try:
@@ -774,22 +790,28 @@ def main():
                    if batcher.delivered[b] >= 0 and batcher.delivered[b] * world + rank < rendered]
         else:
             got = [slabs[b] for b in range(min(n_buf, counter[0]))]
-        for t in got:
-            if not torch.equal(t.view(torch.int32), ref.view(torch.int32)):
-                raise SystemExit(f"[bench] rank {rank}: a collected frame differs from the eager render")
+        bad = any(not torch.equal(t.view(torch.int32), ref.view(torch.int32)) for t in got)
+        collection_failed = ranks_agree_failed(bad, rank, device, "a collected frame differs from the eager render")
+        if collection_failed and not (batched and world > 1):
+            # this WAS the plain gather to rank 0 (or a one-rank rehearsal): nothing simpler to fall back to
+            raise SystemExit("[bench] check FAILED: a collected frame differs from the eager render")
         check_note = f"{len(got)} collected slab(s) equal the eager render bit for bit"
-        if rank == 0:
+        if rank == 0 and not collection_failed:
             print(f"[bench] check ok: {check_note}", file=sys.stderr)
 
     # Multi-GPU runs also report the metric's literal form (one gather per frame to rank 0, equal contiguous slabs) and
     # the measured rate of both collections on this node's links, so the first hardware run replaces the link model of
     # DESIGN.md section 5 with data.  Every rank takes part; outside the timed region above.
     literal = link = None
-    if use_dist and not frames_par and not args.as_rank and os.environ.get("SRH_BENCH_BACKEND", "nccl") == "nccl":
+    if use_dist and not frames_par and not args.as_rank and \
+            (os.environ.get("SRH_BENCH_BACKEND", "nccl") == "nccl" or os.environ.get("SRH_BENCH_LITERAL")):
         already_literal = not batched
         link = measure_exchange(device, rank, world, W, H)
         if not already_literal:
             literal = literal_root0_leg(args, buf, cam, device, rank, world, W, H)
+
+    if collection_failed and literal is None:           # no literal leg in this configuration to fall back to
+        raise SystemExit("[bench] check FAILED: the collected frames differ from the eager render")
 
     timed = [e for e in events if e is not None and (not args.as_rank or args.batch_call != "on")]
     kernel_ms = float(np.mean([e.elapsed_ms() for e in timed])) if timed else 0.0
@@ -878,6 +900,26 @@ def main():
         }
         if literal is not None:
             out["literal_root0"] = literal
+        if literal is not None and (collection_failed or literal["value"] > out["value"]):
+            # Two schedules were run and checked under the same rules (warm-up, exactly --steps frames, barrier on both
+            # sides, max over ranks): the rotating-root default above and the metric's literal form.  The headline is the
+            # faster CORRECT one -- the default has never met real xGMI links, and a schedule whose frames failed the
+            # bit-for-bit check on any rank is not a result at all.  The other one stays visible under its own key.
+            out["other_schedule"] = {"value": out["value"], "ms_per_step": out["ms_per_step"],
+                                     "collection": out["config"]["collection"],
+                                     "rows_per_rank": out["config"]["rows_per_rank"],
+                                     "status": ("bit-for-bit check FAILED on at least one rank; not a result"
+                                                if collection_failed else "checked; slower than the literal form in this run")}
+            out["value"], out["ms_per_step"] = literal["value"], literal["ms_per_step"]
+            out["gtests_per_s"] = literal["value"] * tests / 1e9
+            out["config"].update(collection=literal["collection"], rows_per_rank=literal["rows_per_rank"],
+                                 launch=literal["launch"], frames_in_flight=literal["frames_in_flight"],
+                                 launches="per frame", check=literal["check"])
+            for key in ("roofline", "valu_issue"):     # their kernel time was taken inside the other schedule
+                if out.get(key):
+                    out[key]["note"] = "kernel time measured inside the schedule reported under other_schedule"
+        if use_dist and literal is not None:
+            out["config"]["schedule_choice"] = "two schedules timed and checked in this run; the faster correct one is `value`"
         if link is not None:
             out["links_measured"] = link
         if world == 1 and not args.no_cpu_baseline:
