@@ -40,13 +40,13 @@ VALU_PEAK_GINSTR_S = 614.4
 PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
 
 
-# --schedule auto: the stage schedule is chosen for whole frames whose render kernel takes at least this many times as
-# long as their clear + binning.  Measured at config 5: with the 105 us render kernel (ratio 2.55) stages = frames in
-# steady state and 2 % better over a 20-step timed region; with the typed 88 us kernel (ratio 2.15-2.2) stages is 1-7 %
-# WORSE in steady state (0.0863-0.092 against 0.0851 ms, box to box; measured before the one-wave workgroups) and 0-3 % better over 20 steps -- so it is no
-# longer taken there.  Row slabs (a rank's half frame, ratio 2.1) were 35 % worse in the stage schedule, whose
-# prioritised render streams starve the one binning stream.
-STAGES_MIN_RATIO = 2.3
+# --schedule auto = whole frames per stream, always.  The stage schedule (binning of every frame on one stream, render
+# kernels on two others) was once picked when the render kernel lasted at least 2.3 times as long as clear + binning
+# (equal steady state, 2 % better over a 20-step region with the 105 us kernel, ratio 2.55).  With one-wave workgroups
+# and the typed 88 us kernel it is 30 % WORSE at config 5 (0.1068 against 0.0808 ms per frame, 400 steps; 0.1052 against
+# 0.0867 over 20 steps) -- and the probe sits at ratio 2.16-2.21, 4 % under the old threshold, so a slightly different
+# box would have flipped the default into it.  The probe is still taken and reported (config.schedule_probe);
+# --schedule stages remains for measurements.
 
 
 def load_pmc():
@@ -615,20 +615,15 @@ def main():
         halves = None
         schedule = args.schedule
         if schedule == "auto":
-            # The stage schedule serialises every frame's binning on one stream: right when the render kernel is the
-            # long half (config 5: 100 us against 40), wrong for small frames and row slabs, where three binning chains
-            # side by side are what hides their latency.  Decided by timing one frame's halves.
+            # whole frames per stream (see the note at the top); one frame's halves are timed for the report only
             schedule = "frames"
             if args.mode in ("auto", "binned") and graph_state["on"] and rotate == 1 and n_str >= 3 and \
                     (r0, r1) == (0, H):
                 try:                                   # the library refuses split frames that are not binned
                     bin_ms, render_ms = halves_ms()
                     halves = {"bin_ms": round(bin_ms, 4), "render_ms": round(render_ms, 4)}
-                    if render_ms >= STAGES_MIN_RATIO * bin_ms:
-                        pipe = make_pipe("stages")
-                        schedule = "stages" if pipe.use_graphs else "frames"
                 except (ValueError, _lib.SrhError) as exc:
-                    print(f"[bench] stage schedule not available ({exc}); whole frames per stream", file=sys.stderr)
+                    print(f"[bench] half-frame probe not available ({exc})", file=sys.stderr)
             if schedule == "frames":
                 pipe = make_pipe("frames")
         else:
