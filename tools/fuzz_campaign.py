@@ -1,0 +1,91 @@
+"""One-off parity campaign on a GPU box: random mixed scenes beyond the seeds the test suite fixes.
+
+  python tools/fuzz_campaign.py --seed 1 --seconds 240 [--big]
+
+Per scene: the binned mode (both launch shapes), the row-slab path and the torch-shading variants against the all-pairs
+fp64 mode of the same library, bit for bit (`nearest`, `depth`, `image`), plus -- for small scenes -- the numpy oracle at
+the tests' tolerance.  The scene generator is the test suite's (`tests/test_hip_parity.py: _random_scene`); `--big` draws
+larger frames and more primitives (crowded bins, saturated ordinals).  Prints a progress line every 20 scenes and the
+first failing (seed, scene number), then exits non-zero.  Test infrastructure: the oracle is only the checker here.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--big", action="store_true")
+    args = ap.parse_args()
+    import test_hip_parity as T
+    from surf_renderer_amd import render
+    from surf_renderer_amd.scene import scene_to_numpy
+    from oracle import np_oracle
+
+    rng = np.random.RandomState(args.seed)
+    t0 = time.time()
+    it = n_oracle = 0
+
+    def same(a, b, what):
+        for k in ("nearest", "depth", "image"):
+            x = a[k].cpu().numpy() if torch.is_tensor(a[k]) else a[k]
+            y = b[k].cpu().numpy() if torch.is_tensor(b[k]) else b[k]
+            if not np.array_equal(x, y, equal_nan=True):
+                print(f"FAIL seed {args.seed} scene {it} ({what}): {k} differs on {(x != y).sum()} values", flush=True)
+                sys.exit(1)
+
+    while time.time() - t0 < args.seconds:
+        sc = T._random_scene(rng)
+        if args.big:
+            W, H = int(rng.choice([256, 333, 512, 640])), int(rng.choice([192, 256, 400, 512]))
+            sc["camera"]["viewport"] = [0, 0, W, H]
+            if "disk" in sc["objects"] and rng.randint(2):
+                n = int(rng.choice([20000, 60000]))
+                f32 = lambda a: np.asarray(a, dtype=np.float32)          # noqa: E731
+                sc["objects"]["disk"] = {
+                    "pos": f32(np.concatenate([rng.uniform(-1.5, 1.5, (n, 3)), np.ones((n, 1))], 1)),
+                    "normal": f32(np.concatenate([rng.normal(size=(n, 3)), np.zeros((n, 1))], 1)),
+                    "material_idx": rng.randint(0, 3, n),
+                    "radius": f32(np.exp(rng.uniform(np.log(0.002), np.log(0.2), n)))}
+        H = sc["camera"]["viewport"][3]
+        ref = render(sc, device="cuda:0", mode="exact")
+        for wpt in (1, 4):
+            same(render(sc, device="cuda:0", mode="binned", waves_per_tile=wpt), ref, f"binned wpt {wpt}")
+        r0 = int(rng.randint(0, H - 1))
+        r1 = int(rng.randint(r0 + 1, H + 1))
+        same(render(sc, device="cuda:0", rows=(r0, r1)), {k: ref[k][r0:r1] for k in ("nearest", "depth", "image")},
+             f"rows {r0}:{r1}")
+        sc["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01]], dtype=np.float32)
+        sc["lights"]["ambient"] = np.array([0.01, 0.02, 0.01], dtype=np.float32)
+        sc["materials"]["coeffs"] = np.array([[1, 0, 0], [0.7, 0.3, 5], [0.5, 0.5, 20]], dtype=np.float32)
+        ds = bool(rng.randint(2))
+        same(render(sc, device="cuda:0", mode="binned", shading="torch", double_sided=ds),
+             render(sc, device="cuda:0", mode="exact", shading="torch", double_sided=ds), "torch shading")
+        W = sc["camera"]["viewport"][2]
+        if not args.big and W * H <= 64 * 80 and sum(len(g["material_idx"]) for g in sc["objects"].values()) <= 800:
+            for k in ("attenuation", "ambient"):
+                sc["lights"].pop(k)
+            sc["materials"].pop("coeffs")
+            T.assert_parity({k: ref[k].cpu().numpy() for k in ("image", "depth", "nearest")},
+                            np_oracle.render(scene_to_numpy(sc, round_fp32=True)))
+            n_oracle += 1
+        it += 1
+        if it % 20 == 0:
+            print(f"[fuzz seed {args.seed}{' big' if args.big else ''}] {it} scenes ok ({n_oracle} also against the "
+                  f"oracle), {time.time() - t0:.0f} s", flush=True)
+    print(f"[fuzz seed {args.seed}{' big' if args.big else ''}] DONE: {it} scenes, {n_oracle} against the oracle, "
+          f"all identical", flush=True)
+
+
+if __name__ == "__main__":
+    main()
