@@ -224,7 +224,9 @@ def test_fuzz_backward_against_the_gradient_oracles():
     from surf_renderer_amd import render
     from surf_renderer_amd.scene import scene_to_numpy
     from test_hip_parity import _random_scene
-    rng = np.random.RandomState(41)
+    # SRH_FUZZ_BWD_SEED / SRH_FUZZ_BWD_SCENES: one-off campaigns with other seeds (profiles/r02_fuzz_campaign.txt)
+    rng = np.random.RandomState(int(os.environ.get("SRH_FUZZ_BWD_SEED", "41")))
+    n_scenes = int(os.environ.get("SRH_FUZZ_BWD_SCENES", "40"))
 
     def compare(tag, got, want, tol):
         for key, w in want.items():
@@ -233,7 +235,7 @@ def test_fuzz_backward_against_the_gradient_oracles():
             np.testing.assert_allclose(g, w, rtol=0, atol=tol * max(np.abs(w).max(), 1e-9) + 1e-6, err_msg=f"{tag} {key}")
 
     done = 0
-    while done < 40:
+    while done < n_scenes:
         scene = _random_scene(rng)
         W, H = scene["camera"]["viewport"][2:]
         if W * H > 64 * 80 or sum(len(g["material_idx"]) for g in scene["objects"].values()) > 400:
