@@ -220,9 +220,15 @@ def literal_root0_leg(args, buf, cam, device, rank, world, W, H):
             if not torch.equal(frames[b].view(torch.int32), ref.view(torch.int32)):
                 ok.zero_()
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok.item()) < 1.0:
-        raise SystemExit("[bench] literal gather-to-rank-0 leg: an assembled frame differs from the eager full-frame render")
     el = float(el.item())
+    if float(ok.item()) < 1.0:
+        # not fatal by itself: the caller keeps the default schedule's (checked) result and shows this leg as failed
+        if rank == 0:
+            print("[bench] literal gather-to-rank-0 leg: an assembled frame differs from the eager full-frame render",
+                  file=sys.stderr)
+        return {"failed": True, "value": args.steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / args.steps,
+                "collection": "gather to rank 0 per frame (one collective per frame)",
+                "check": "FAILED: an assembled frame differs from the eager full-frame render; not a result"}
     return {"value": args.steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / args.steps,
             "collection": "gather to rank 0 per frame (one collective per frame)",
             "rows_per_rank": "one contiguous slab, equal split", "launch": "eager", "frames_in_flight": n_buf,
@@ -805,7 +811,7 @@ def main():
         if not already_literal:
             literal = literal_root0_leg(args, buf, cam, device, rank, world, W, H)
 
-    if collection_failed and literal is None:           # no literal leg in this configuration to fall back to
+    if collection_failed and (literal is None or literal.get("failed")):   # nothing correct to fall back to
         raise SystemExit("[bench] check FAILED: the collected frames differ from the eager render")
 
     timed = [e for e in events if e is not None and (not args.as_rank or args.batch_call != "on")]
@@ -895,7 +901,7 @@ def main():
         }
         if literal is not None:
             out["literal_root0"] = literal
-        if literal is not None and (collection_failed or literal["value"] > out["value"]):
+        if literal is not None and not literal.get("failed") and (collection_failed or literal["value"] > out["value"]):
             # Two schedules were run and checked under the same rules (warm-up, exactly --steps frames, barrier on both
             # sides, max over ranks): the rotating-root default above and the metric's literal form.  The headline is the
             # faster CORRECT one -- the default has never met real xGMI links, and a schedule whose frames failed the
