@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--shadows", action="store_true",
+                    help="instead: the shadow pass with candidates from light-space tile bins against its all-pairs form "
+                         "(visibility bits and re-shaded image bit for bit), random lights incl. inside the cloud")
     args = ap.parse_args()
     import test_hip_parity as T
     from surf_renderer_amd import render
@@ -43,6 +46,35 @@ def main():
             if not np.array_equal(x, y, equal_nan=True):
                 print(f"FAIL seed {args.seed} scene {it} ({what}): {k} differs on {(x != y).sum()} values", flush=True)
                 sys.exit(1)
+
+    if args.shadows:
+        import test_hip_torch_shading as TS
+        n_shadowed = 0
+        while time.time() - t0 < args.seconds:
+            sc = T._random_scene(rng)
+            sc["camera"]["near"] = max(sc["camera"]["near"], 0.01)
+            n_l = int(rng.randint(1, 5))
+            lp = rng.normal(size=(n_l, 3))
+            lp = lp / np.linalg.norm(lp, axis=1, keepdims=True) * rng.choice([0.2, 1.0, 2.5, 6.0, 12.0], size=(n_l, 1))
+            sc["lights"] = {"pos": np.concatenate([lp, np.ones((n_l, 1))], 1).astype(np.float32),
+                            "color_idx": rng.randint(1, 3, n_l)}
+            sc = TS._with_torch_inputs(sc)
+            kw = {"double_sided": bool(rng.randint(2)), "use_quartic": bool(rng.randint(2))}
+            (img_b, vis_b, depth), (img_a, vis_a, _) = TS._shadow_both_ways(sc, **kw)
+            if not torch.equal(vis_b, vis_a) or not torch.equal(img_b.view(torch.int32), img_a.view(torch.int32)):
+                print(f"FAIL seed {args.seed} scene {it} (shadows {kw}): visibility differs on "
+                      f"{int((vis_b != vis_a).sum())} pixels, image on "
+                      f"{int((img_b.view(torch.int32) != img_a.view(torch.int32)).sum())} values", flush=True)
+                sys.exit(1)
+            hit = depth <= float(sc["camera"]["far"])
+            n_shadowed += int(((vis_a[hit] & ((1 << n_l) - 1)) != (1 << n_l) - 1).sum())
+            it += 1
+            if it % 20 == 0:
+                print(f"[fuzz seed {args.seed} shadows] {it} scenes ok, {n_shadowed} shadowed pixels so far, "
+                      f"{time.time() - t0:.0f} s", flush=True)
+        print(f"[fuzz seed {args.seed} shadows] DONE: {it} scenes, {n_shadowed} shadowed pixels, binned = all pairs "
+              f"bit for bit", flush=True)
+        return
 
     while time.time() - t0 < args.seconds:
         sc = T._random_scene(rng)
