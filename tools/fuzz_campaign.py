@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--shadows", action="store_true",
                     help="instead: the shadow pass with candidates from light-space tile bins against its all-pairs form "
                          "(visibility bits and re-shaded image bit for bit), random lights incl. inside the cloud")
+    ap.add_argument("--views", action="store_true",
+                    help="instead: render_views (one batch of 2-5 random cameras, perspective or orthographic under torch "
+                         "shading) against per-view render(), bit for bit")
     args = ap.parse_args()
     import test_hip_parity as T
     from surf_renderer_amd import render
@@ -46,6 +49,35 @@ def main():
             if not np.array_equal(x, y, equal_nan=True):
                 print(f"FAIL seed {args.seed} scene {it} ({what}): {k} differs on {(x != y).sum()} values", flush=True)
                 sys.exit(1)
+
+    if args.views:
+        from surf_renderer_amd import render_views
+        while time.time() - t0 < args.seconds:
+            sc = T._random_scene(rng)
+            kw = {}
+            if rng.randint(2):
+                sc["lights"]["attenuation"] = np.array([[1, 0, 0], [0.5, 0.1, 0.01]], dtype=np.float32)
+                sc["lights"]["ambient"] = np.array([0.01, 0.02, 0.01], dtype=np.float32)
+                sc["materials"]["coeffs"] = np.array([[1, 0, 0], [0.7, 0.3, 5], [0.5, 0.5, 20]], dtype=np.float32)
+                kw = {"shading": "torch", "double_sided": bool(rng.randint(2))}
+                if rng.randint(2):
+                    sc["camera"]["proj_type"] = "ortho"
+                    sc["camera"]["near"] = max(sc["camera"]["near"], 0.01)
+            cams = []
+            for _ in range(int(rng.randint(2, 6))):
+                e = rng.normal(size=3)
+                e = e / np.linalg.norm(e) * rng.choice([0.5, 2.0, 3.0, 6.0])
+                cams.append(dict(sc["camera"], eye=[*map(float, e), 1.0]))
+            vb = render_views(sc, cams, device="cuda:0", **kw)
+            for i, cam in enumerate(cams):
+                one = render({**sc, "camera": cam}, device="cuda:0", **kw)
+                same({"image": vb["image"][i], "depth": vb["depth"][i], "nearest": vb["nearest"][i].to(torch.int64)},
+                     one, f"view {i} of {len(cams)} {kw} {sc['camera'].get('proj_type', 'perspective')}")
+            it += 1
+            if it % 20 == 0:
+                print(f"[fuzz seed {args.seed} views] {it} batches ok, {time.time() - t0:.0f} s", flush=True)
+        print(f"[fuzz seed {args.seed} views] DONE: {it} batches of 2-5 views, all equal to per-view renders", flush=True)
+        return
 
     if args.shadows:
         import test_hip_torch_shading as TS
