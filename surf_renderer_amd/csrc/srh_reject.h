@@ -161,6 +161,43 @@ __device__ inline float ball_inverse_depth_bound(const double oc[3], double r) {
   return (inv < 1.0e30) ? (float)inv * 1.0000002f : 1.0e30f;
 }
 
+// Can the six fp64 coefficients of a conic be trusted?  `tmax` = largest |T_ij|, `emax` = largest sum of the absolute
+// values of the terms T_ij was formed from (before they cancelled): the evaluation error is a few 2^-53 emax, and the
+// margins of conic_record cover coefficient errors of 2^-26 of the conic's scale -- so trust needs tmax > 2^-24 emax.
+// The entries live on different scales (x = (1, c, r): T_ij carries |Pi| |Pj|, and |Dc| is a pixel pitch), so both are
+// taken in units of |Pi| |Pj|.
+// (A disc with centre y = -1e20 and radius 1e20 passes through the scene, |oc|^2 and r^2 agree to the last bit, and
+// the coefficients are rounding noise that happened to look like a small ellipse; found by the non-finite fuzz with
+// seed 2002.)  Not trusted -> the record stays "always a candidate".
+__device__ inline bool conic_trusted(double tmax, double emax) {
+  return isfinite(emax) && tmax * 16777216.0 > emax;
+}
+__device__ inline double abs_dot3(const double* a, const double* b) {
+  return fabs(a[0] * b[0]) + fabs(a[1] * b[1]) + fabs(a[2] * b[2]);
+}
+
+// sphere silhouette  cq (Pi.Pj) - (oc.Pi)(oc.Pj)  with the trust test; `sq` = magnitude of the terms cq was formed from
+__device__ inline void sphere_conic_record(const double oc[3], double cq, double sq, const double* const P[3], int W, int H,
+                                           float* out) {
+  double w[3], mw[3], is[3];
+  for (int j = 0; j < 3; ++j) {
+    w[j] = dot3(oc, P[j]); mw[j] = abs_dot3(oc, P[j]);
+    const double l = sqrt(dot3(P[j], P[j]));
+    is[j] = (l > 0.0) ? 1.0 / l : 0.0;                    // entries are compared in units of |Pi| |Pj| (see below)
+  }
+  double t[6], tmax = 0.0, emax = 0.0;
+  int q = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 3; ++j, ++q) {
+      t[q] = cq * dot3(P[i], P[j]) - w[i] * w[j];
+      tmax = fmax(tmax, fabs(t[q]) * (is[i] * is[j]));
+      emax = fmax(emax, (sq * abs_dot3(P[i], P[j]) + mw[i] * fabs(w[j]) + mw[j] * fabs(w[i]) + fabs(w[i] * w[j])) *
+                            (is[i] * is[j]));
+    }
+  if (!conic_trusted(tmax, emax)) { rec_zero(out, 5); out[11] = 0.0f; return; }
+  (void)conic_record(t[0], t[1], t[2], t[3], t[4], t[5], W, H, out);
+}
+
 // disc: | oc (n.D) + k D |^2 <= r^2 (n.D)^2   (numpy/renderer.py:69,85-88 with t = k / (n.D))
 __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, int W, int H, float* out) {
   const double* n = R;
@@ -168,22 +205,37 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
   const double* oc = R + 4;
   const double r2 = R[7];
   const double* P[3] = {B.D0, B.Dc, B.Dr};
-  double nu[3], u[3][3];
+  double nu[3], u[3][3], mu[3], au[3], is[3];   // mu: |terms of u| summed over the components, au: |u| (L1)
   for (int j = 0; j < 3; ++j) {
     nu[j] = dot3(n, P[j]);
-    for (int a = 0; a < 3; ++a) u[j][a] = oc[a] * nu[j] + k * P[j][a];
+    mu[j] = au[j] = 0.0;
+    const double l = sqrt(dot3(P[j], P[j]));
+    is[j] = (l > 0.0) ? 1.0 / l : 0.0;
+    for (int a = 0; a < 3; ++a) {
+      u[j][a] = oc[a] * nu[j] + k * P[j][a];
+      mu[j] += fabs(oc[a] * nu[j]) + fabs(k * P[j][a]);
+      au[j] += fabs(u[j][a]);
+    }
   }
-  auto T = [&](int i, int j) { return dot3(u[i], u[j]) - r2 * nu[i] * nu[j]; };
-  const bool degenerate = conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out) < 0.0;
+  double t[6], tmax = 0.0, emax = 0.0;
+  {
+    int q = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = i; j < 3; ++j, ++q) {
+        t[q] = dot3(u[i], u[j]) - r2 * nu[i] * nu[j];
+        tmax = fmax(tmax, fabs(t[q]) * (is[i] * is[j]));
+        emax = fmax(emax, (mu[i] * au[j] + mu[j] * au[i] + abs_dot3(u[i], u[j]) + fabs(r2 * nu[i] * nu[j])) *
+                              (is[i] * is[j]));
+      }
+  }
+  bool degenerate = true;
+  if (conic_trusted(tmax, emax)) degenerate = conic_record(t[0], t[1], t[2], t[3], t[4], t[5], W, H, out) < 0.0;
   if (degenerate) {
     // The disc's own image is not a usable ellipse (seen edge-on: axis ratio beyond 512, parameters are noise).
     // Every hit lies on the disc, hence inside the sphere around its centre with its radius, and that sphere's
     // silhouette is a robust, well-conditioned ellipse.  Rare (|cos| < 2e-3), so the extra work is off the common path.
-    const double cq = dot3(oc, oc) - r2;
-    double w[3];
-    for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
-    auto Ts = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
-    (void)conic_record(Ts(0, 0), Ts(0, 1), Ts(0, 2), Ts(1, 1), Ts(1, 2), Ts(2, 2), W, H, out);
+    const double oo = dot3(oc, oc);
+    sphere_conic_record(oc, oo - r2, oo + fabs(r2), P, W, H, out);
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
@@ -215,8 +267,8 @@ __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B
   const double* P[3] = {B.D0, B.Dc, B.Dr};
   double w[3];
   for (int j = 0; j < 3; ++j) w[j] = dot3(oc, P[j]);
-  auto T = [&](int i, int j) { return cq * dot3(P[i], P[j]) - w[i] * w[j]; };
-  conic_record(T(0, 0), T(0, 1), T(0, 2), T(1, 1), T(1, 2), T(2, 2), W, H, out);
+  // cq = |oc|^2 - r^2 comes from the exact record: the terms it was formed from are at most 2 |oc|^2 + |cq|
+  sphere_conic_record(oc, cq, 2.0 * dot3(oc, oc) + fabs(cq), P, W, H, out);
   // Depth bound.  Eye outside the sphere (cq > 0): both roots have the sign of (pos - eye).D = -oc.D.  Positive roots
   // give t = t1 >= |oc| - r.  Negative roots are a miss under the torch semantics, but the numpy backend's sentinel
   // turns them into t = 1.0 (Q2) -- so there the bound holds only if -oc.D > 0 on the whole image (affine: its

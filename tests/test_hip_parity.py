@@ -558,8 +558,9 @@ def test_fuzz_non_finite_and_degenerate_primitives():
     normal component: every mode gives the all-pairs fp64 result bit for bit (nan-aware), and small ones match the
     numpy oracle -- whose comparisons drop a nan hit exactly as `near <= t` does in the reference (numpy/renderer.py:219)."""
     from surf_renderer_amd.scene import scene_to_numpy
-    rng = np.random.RandomState(71)
-    for it in range(60):
+    # SRH_FUZZ_NONFINITE_SEED / _SCENES: one-off campaigns with other seeds (profiles/r02_fuzz_campaign.txt)
+    rng = np.random.RandomState(int(os.environ.get("SRH_FUZZ_NONFINITE_SEED", "71")))
+    for it in range(int(os.environ.get("SRH_FUZZ_NONFINITE_SCENES", "60"))):
         scene = _random_scene(rng)
         _poison(rng, scene, float(rng.choice([0.02, 0.2, 0.5])))
         ref = _render(scene, mode="exact")
@@ -578,6 +579,38 @@ def test_fuzz_non_finite_and_degenerate_primitives():
                 ok = np.isclose(img, want["image"], rtol=IMAGE_RTOL, atol=IMAGE_ATOL, equal_nan=True) | \
                     ((np.abs(want["image"]) > 3e38) & np.isinf(img))          # beyond float32 on our side
                 assert ok.all(), f"scene {it}: image differs from the oracle on {(~ok).sum()} values"
+
+
+@pytest.mark.gpu
+def test_disc_whose_conic_coefficients_cancel_is_not_rejected():
+    """Found by the non-finite fuzz with seed 2002 (scene 2425): a disc with centre y = -1e20 and radius -1e20 passes
+    through the scene (|oc|^2 and r^2 agree to the last bit, the reference's fp64 test says hit), but the fp64
+    coefficients of its image conic were rounding noise that looked like a small well-conditioned ellipse, and every
+    accelerated mode rejected 166 pixels of it.  The reject record now checks how much of the coefficients survived
+    the cancellation (srh_reject.h: conic_trusted) and stays "always a candidate" otherwise."""
+    f32 = lambda a: np.asarray(a, dtype=np.float32)          # noqa: E731
+    scene = {
+        "camera": {"viewport": [0, 0, 200, 80], "fovy": 0.3490658503988659, "focal_length": 0.5,
+                   "eye": [-0.22518337330819965, -0.17873926241833957, -0.08570136787524409, 1.0],
+                   "at": [-0.052733267564547964, -0.40446551969026406, -0.02202172392123179, 1.0],
+                   "up": [0.8508139646210928, 0.6642066983782233, 0.4076471168705725, 0.0], "near": 1.0, "far": 50.0},
+        "lights": {"pos": f32([[3, 4, 5, 1], [-4, 2, 3, 1]]), "color_idx": np.array([1, 2])},
+        "colors": f32([[0, 0, 0], [.8, .5, .4], [.3, .6, .9]]),
+        "materials": {"albedo": f32([[.5, .5, .5], [.9, .3, .2]])},
+        "objects": {"disk": {
+            "pos": f32([[1.0083192586898804, -0.6783924698829651, -0.0375119112432003, 1.0],
+                        [0.29687345027923584, -1.0000000200408773e+20, 0.36714065074920654, 1.0]]),
+            "normal": f32([[-0.18393109738826752, 0.6064280867576599, 1.0000000031710769e-30, 0.0],
+                           [-0.05883683264255524, 3.000000645916e-39, -0.07081481069326401, 0.0]]),
+            "radius": f32([1.0000000200408773e+20, -1.0000000200408773e+20]),
+            "material_idx": np.array([0, 1])}},
+        "tonemap": {"type": "gamma", "gamma": 0.8}}
+    ref = _render(scene, mode="exact")
+    assert (ref["nearest"] == 1).sum() > 100                 # the huge disc is what most pixels see
+    for mode, wpt in (("fast", 0), ("binned", 1), ("binned", 4)):
+        got = _render(scene, mode=mode, waves_per_tile=wpt)
+        for k in ("nearest", "depth", "image"):
+            assert np.array_equal(got[k], ref[k], equal_nan=True), f"{mode}/{wpt}: {k} differs"
 
 
 @pytest.mark.gpu
