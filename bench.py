@@ -126,6 +126,10 @@ def parse():
                          "for bit, with a fresh eager render of the same rows and exit non-zero on a mismatch (stream / "
                          "graph / collective ordering self-test; outside the timed region)")
     ap.add_argument("--no-check", dest="check", action="store_false")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="multi-GPU: when the default collection schedule fails its bit-for-bit check and the headline "
+                         "falls back to the literal gather-to-rank-0 form, exit 0 anyway (the line still carries "
+                         "check_failed: true).  Without this flag such a run prints its line and exits 3")
     ap.add_argument("--warmup-ms", type=float, default=150.0,
                     help="after the --warmup steps keep submitting untimed frames until this much wall time has passed "
                          "since the first warm-up frame, so that a short run is timed at ramped clocks")
@@ -925,10 +929,16 @@ def main():
             out["links_measured"] = link
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, M, W, H, args.cpu_pixels)
+        if collection_failed:
+            # a schedule that RAN failed its check: the numbers above are the literal form's (which passed), but a
+            # correctness failure of the production collection path must not read as a passing benchmark
+            out["check_failed"] = True
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if collection_failed and not args.allow_fallback:     # agreed on by every rank (ranks_agree_failed)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,27 @@ import numpy as np
 
 
 # ------------------------------------------------------------------------------------------
+# The reference's four matrix products (numpy/renderer.py:20,64,69,160) go through np.dot, i.e. the BLAS of the
+# machine, whose dgemm kernels accumulate with fused multiply-adds in an order of their own: the last bit of such a
+# product is a property of the BLAS build, not of the algorithm.  `render(..., dots="ordered")` evaluates the same
+# products as explicit sums, ((a0 b0 + a1 b1) + a2 b2) + a3 b3 with every operation rounded -- the order the hip
+# backend documents for its fp64 path (srh_device.h: dot3).  Both variants are checked against the reference's golden
+# outputs (tests/test_oracle_golden.py); they differ only where a result is decided by the last bit of a cancelling sum
+# (tests/test_hip_adversarial.py compares the GPU with the ordered variant, and the two variants with each other).
+# ------------------------------------------------------------------------------------------
+_DOTS = "blas"
+
+
+def _dot(a, b):
+    """np.dot(a, b) for a (M,4) or (4,4) and b (4,) or (4,n) -- or the same contraction in a fixed order."""
+    if _DOTS == "blas":
+        return np.dot(a, b)
+    b2 = b if b.ndim == 2 else b[:, np.newaxis]
+    out = ((a[:, 0:1] * b2[0:1] + a[:, 1:2] * b2[1:2]) + a[:, 2:3] * b2[2:3]) + a[:, 3:4] * b2[3:4]
+    return out if b.ndim == 2 else out[:, 0]
+
+
+# ------------------------------------------------------------------------------------------
 # numpy/ops.py helpers
 # ------------------------------------------------------------------------------------------
 def nonzero_divide(x, y):
@@ -76,7 +97,7 @@ def generate_rays(camera, dtype=np.float64):
     y *= h / 2
     eye = np.array(camera['eye'])
     d = np.stack((x.ravel(), y.ravel(), -np.ones(x.size) * focal, np.zeros(x.size)), axis=0)
-    d = np.dot(lookat_inv(eye=eye, at=camera['at'], up=camera['up']), d)
+    d = _dot(lookat_inv(eye=eye, at=camera['at'], up=camera['up']), d)
     d /= np.sqrt(np.sum(d ** 2, axis=0))
     return eye.astype(dtype), d.astype(dtype), H, W
 
@@ -94,8 +115,8 @@ def hit_plane(eye, d, pos, normal):
     rejected later by the near/far test)."""
     n = normalize(normal)
     dist = np.sum(pos * n, axis=1)
-    denom = np.dot(n, d)
-    return (dist[:, np.newaxis] - np.dot(n, eye)[:, np.newaxis]) / denom
+    denom = _dot(n, d)
+    return (dist[:, np.newaxis] - _dot(n, eye)[:, np.newaxis]) / denom
 
 
 def hit_disk(eye, d, pos, normal, radius):
@@ -129,7 +150,7 @@ def hit_sphere(eye, d, pos, radius):
     t = 0."""
     oc = eye - pos
     a = np.sum(d ** 2, axis=0)
-    b = 2 * np.dot(oc, d)
+    b = 2 * _dot(oc, d)
     c = (np.sum(oc ** 2, axis=1) - radius ** 2)[:, np.newaxis]
     disc = b ** 2 - 4 * a * c
     ok = disc >= 0
@@ -180,7 +201,18 @@ def _winner_normals(segs, nearest, p_win, eye, d, dtype):
     return out
 
 
-def render(scene, tile=2048, dtype=np.float64, rows=None, window=None):
+def render(scene, tile=2048, dtype=np.float64, rows=None, window=None, dots="blas"):
+    """See _render; ``dots`` = "blas" (np.dot, as the reference) or "ordered" (explicit sums, see the top of the file)."""
+    global _DOTS
+    assert dots in ("blas", "ordered")
+    prev, _DOTS = _DOTS, dots
+    try:
+        return _render(scene, tile, dtype, rows, window)
+    finally:
+        _DOTS = prev
+
+
+def _render(scene, tile=2048, dtype=np.float64, rows=None, window=None):
     """Restatement of numpy/renderer.py:204-272 for the ndarray-leaf scene dict the reference
     consumes.  ``rows=(r0, r1)`` renders only image rows [r0, r1) of the full camera (outputs then
     have r1 - r0 rows); ``window=(p0, p1)`` renders only the flat pixel range [p0, p1) of the row-major image

@@ -56,7 +56,10 @@ __device__ inline bool ball_misses_slab(const FrameDev& F, const double x[3], do
   const double a0 = dot3(F.slab_ma, x), g0 = dot3(F.slab_mg, x);
   const double a_lo = a0 - rho * F.slab_na, a_hi = a0 + rho * F.slab_na;
   const double g_lo = g0 - rho * F.slab_ng, g_hi = g0 + rho * F.slab_ng;
-  if (!(a_lo > 0.0) || !isfinite(a_hi + g_lo + g_hi)) return false;
+  // fp64 side: a0 and g0 carry 2^-52 of their absolute terms.  The cull is used only while a_lo keeps 1e-6 of them
+  // (relative error of a below 2^-32, of the rows below 1e-6 of a row: inside the half-row slack); a ball that far off
+  // axis, or that cancelled (centre ~1e20 away, radius to match), is simply kept
+  if (!(a_lo > 1.0e-6 * (abs_dot3(F.slab_ma, x) + rho * F.slab_na)) || !isfinite(a_hi + g_lo + g_hi)) return false;
   const double r_lo = g_lo / (g_lo >= 0.0 ? a_hi : a_lo), r_hi = g_hi / (g_hi >= 0.0 ? a_lo : a_hi);
   return r_hi < (double)F.row0 - 0.5 || r_lo > (double)F.row1 - 0.5;
 }
@@ -120,7 +123,7 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
   float Q[N32];
   const PixelBasis B = pixel_basis(F);
   const bool near_pos = F.near_clip > 0.0;
-  if (TYPE == SRH_PRIM_DISK) disk_reject_record(R, B, F.W, F.H, Q);
+  if (TYPE == SRH_PRIM_DISK) disk_reject_record(R, F.o, B, F.W, F.H, Q);
   else if (TYPE == SRH_PRIM_SPHERE) sphere_reject_record(R, B, F.W, F.H, near_pos, F.shading != 0, Q);
   else if (TYPE == SRH_PRIM_TRIANGLE) triangle_reject_record(R, F.o, B, F.W, F.H, near_pos, Q);
   else plane_reject_record(R, B, F.W, F.H, Q);
@@ -139,7 +142,10 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
     bool near_eye = false;
     if (F.near_ball > 0.0) {
       double dmin = 0.0;
-      if (TYPE == SRH_PRIM_DISK) dmin = sqrt(dot3(R + 4, R + 4)) - sqrt(fabs(R[7]));
+      if (TYPE == SRH_PRIM_DISK) {
+        const double oc[3] = {F.o[0] - R[4], F.o[1] - R[5], F.o[2] - R[6]};
+        dmin = sqrt(dot3(oc, oc)) - sqrt(fabs(R[7]));
+      }
       else if (TYPE == SRH_PRIM_SPHERE) dmin = sqrt(dot3(R, R)) - sqrt(fabs(dot3(R, R) - R[3]));
       else if (TYPE == SRH_PRIM_TRIANGLE) {
         double far2 = 0.0, near2 = 1.0e300;
@@ -163,18 +169,21 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
   }
 }
 
+// Four waves per SIMD (at most 128 VGPRs), asked for explicitly: left alone hipcc takes what it likes -- 150 registers for
+// the disc instantiation once the fp64 trust terms of srh_reject.h went in, three waves per SIMD -- and the prep waves of
+// the frames in flight then hold their slots longer beside the render waves: config 5 went from 0.078 to 0.093 ms per
+// frame on that alone.  At 128 the compiler needs no spills.
 #ifndef SRH_PREP_WAVES
-#define SRH_PREP_ATTR
-#else
-#define SRH_PREP_ATTR __attribute__((amdgpu_waves_per_eu(SRH_PREP_WAVES)))
+#define SRH_PREP_WAVES 4
 #endif
+#define SRH_PREP_ATTR __attribute__((amdgpu_waves_per_eu(SRH_PREP_WAVES)))
 template <int TYPE>
 __global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
   prep_body<TYPE>(F, s, rec64, rec32);
 }
 
 template <int TYPE>
-__global__ __launch_bounds__(kBinBlock) void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
+__global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep_views(const FrameDev* __restrict__ Fs, int s) {
   const FrameDev& F = Fs[blockIdx.y];
   prep_body<TYPE>(F, s, const_cast<double*>(F.seg[s].rec64), const_cast<float*>(F.seg[s].rec32));
 }
@@ -232,7 +241,7 @@ __device__ __forceinline__ void prep_record64(const SegDev& S, int type, int i, 
   R[3] = dist - neye;
   if (type == SRH_PRIM_DISK) {
     const double r = (double)S.radius[i];
-    R[4] = o[0] - p[0]; R[5] = o[1] - p[1]; R[6] = o[2] - p[2];
+    R[4] = p[0]; R[5] = p[1]; R[6] = p[2];
     R[7] = r * r;
   } else if (type == SRH_PRIM_TRIANGLE) {
     const float* f = S.face + 12 * (size_t)i;

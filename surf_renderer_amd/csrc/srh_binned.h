@@ -52,8 +52,10 @@ __device__ inline TileBox bin_primitive(const FrameDev& F, int seg, int type, co
     is_large = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaxTilesPerPrim;
   }
   if (is_large) {                                                 // the batch's region of `large` starts at seg.first
+    // bounded like the bin lists: whatever the counter holds (a workspace whose counters were never cleared), the
+    // store stays inside the batch's region -- every primitive joins at most once, so a clean counter never exceeds it
     const uint32_t slot = atomicAdd(&F.counters[seg], 1u);
-    F.large[F.seg[seg].first + slot] = (uint32_t)gidx;
+    if (slot < (uint32_t)F.seg[seg].count) F.large[F.seg[seg].first + slot] = (uint32_t)gidx;
     return TileBox{1, 0, 0, 0};
   }
   tr[0] = (uint16_t)tx0; tr[1] = (uint16_t)ty0; tr[2] = (uint16_t)tx1; tr[3] = (uint16_t)ty1;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, 
   for (int m = 1; m < kLanes; m <<= 1) over |= __shfl_xor(over, m);
   if (sub == 0 && over) {
     const uint32_t at = atomicAdd(&F.counters[seg], 1u);
-    F.large[first + at] = (uint32_t)gidx;
+    if (at < (uint32_t)F.seg[seg].count) F.large[first + at] = (uint32_t)gidx;
   }
 }
 
@@ -169,6 +171,11 @@ __device__ __forceinline__ const uint32_t* bin_list(const FrameDev& F, int bin) 
 }
 __device__ __forceinline__ uint32_t bin_length(const FrameDev& F, int bin) {
   return min(F.counters[kCounterPad + bin], (uint32_t)F.bin_cap);
+}
+
+// length of batch s's frame-wide list, clamped to the batch like bin_length to the bin: reads stay inside the workspace
+__device__ __forceinline__ uint32_t large_length(const FrameDev& F, int s) {
+  return min(F.counters[s], (uint32_t)F.seg[s].count);
 }
 
 __global__ __launch_bounds__(kBinBlock) void k_bin_count(FrameDev F) { bin_count_body(F); }
@@ -344,14 +351,14 @@ struct FrontRecord {
   __device__ __forceinline__ double hit(const FrameDev& F, const double d[3]) const {
     if ((BATCH >= 0) || F.nseg == 1) {               // wave-uniform type: a scalar branch picks the intersection
       switch (BATCH >= 0 ? BATCH : F.seg[0].type) {
-        case SRH_PRIM_DISK: return hit_disk64(v, d);
+        case SRH_PRIM_DISK: return hit_disk64(v, F.o, d);
         case SRH_PRIM_PLANE: return hit_plane64(v, d);
         case SRH_PRIM_SPHERE: return TCH ? hit_sphere64_tch(v, d) : hit_sphere64(v, d);
         default: return hit_triangle64(R, F.o, d);
       }
     }
     switch (type) {
-      case SRH_PRIM_DISK: return hit_disk64(v, d);
+      case SRH_PRIM_DISK: return hit_disk64(v, F.o, d);
       case SRH_PRIM_PLANE: return hit_plane64(v, d);
       case SRH_PRIM_SPHERE: return TCH ? hit_sphere64_tch(v, d) : hit_sphere64(v, d);
       default: return hit_triangle64(R, F.o, d);
@@ -654,7 +661,7 @@ struct TileLists {
     return 0;
 #else
     const int bin = s * F.ntiles_pad + tile;
-    return pass == 0 ? F.counters[s] : bin_length(F, bin);
+    return pass == 0 ? large_length(F, s) : bin_length(F, bin);
 #endif
   }
 };

@@ -78,7 +78,7 @@ struct FrameDev {
 };
 
 // rec64 layouts
-//   disk     [0..2] n^ (unit normal)  [3] k = sum(pos*n^) - n^.eye  [4..6] oc = eye - pos  [7] r^2
+//   disk     [0..2] n^ (unit normal)  [3] k = sum(pos*n^) - n^.eye  [4..6] c = pos  [7] r^2
 //   plane    [0..2] n^                [3] k
 //   sphere   [0..2] oc = eye - pos    [3] c = |oc|^2 - r^2
 //   triangle [0..2] n^ [3] k [4..12] v0,v1,v2 (xyz) [13..21] e01,e12,e20 [22..23] pad
@@ -140,10 +140,12 @@ __device__ __forceinline__ double hit_plane64(const double* R, const double d[3]
   return R[3] / dot3(R, d);
 }
 
-// disk: numpy/renderer.py:77-93 -- plane hit kept where |p - c|^2 <= r^2, else inf
-__device__ __forceinline__ double hit_disk64(const double* R, const double d[3]) {
+// disk: numpy/renderer.py:77-93 -- plane hit kept where |p - c|^2 <= r^2, else inf.  In the reference's order of
+// operations, p = eye + t d first and the centre subtracted from it (:5-6, :85): with a centre ~1e15 away that rounds
+// differently from (eye - c) + t d, and the rim of such a disc is decided by exactly that rounding.
+__device__ __forceinline__ double hit_disk64(const double* R, const double o[3], const double d[3]) {
   const double t = R[3] / dot3(R, d);
-  const double qx = R[4] + t * d[0], qy = R[5] + t * d[1], qz = R[6] + t * d[2];
+  const double qx = (o[0] + t * d[0]) - R[4], qy = (o[1] + t * d[1]) - R[5], qz = (o[2] + t * d[2]) - R[6];
   const double dist_sqr = (qx * qx + qy * qy) + qz * qz;
   return (dist_sqr <= R[7]) ? t : __builtin_inf();
 }
@@ -199,7 +201,7 @@ __device__ __forceinline__ double hit_sphere64_tch(const double* R, const double
 __device__ __forceinline__ double hit_any64(int type, const double* R, const double o[3], const double d[3],
                                             bool tch = false) {
   switch (type) {
-    case SRH_PRIM_DISK: return hit_disk64(R, d);
+    case SRH_PRIM_DISK: return hit_disk64(R, o, d);
     case SRH_PRIM_PLANE: return hit_plane64(R, d);
     case SRH_PRIM_SPHERE: return tch ? hit_sphere64_tch(R, d) : hit_sphere64(R, d);
     default: return hit_triangle64(R, o, d);
@@ -207,7 +209,8 @@ __device__ __forceinline__ double hit_any64(int type, const double* R, const dou
 }
 
 // The same intersections for a ray that starts at eye + q instead of at the eye (orthographic projection, torch
-// semantics): the eye-relative records shift by q -- k' = k - n^.q, oc' = oc + q, |oc'|^2 - r^2 = c + 2 oc.q + |q|^2.
+// semantics): the eye-relative records shift by q -- k' = k - n^.q, oc' = oc + q, |oc'|^2 - r^2 = c + 2 oc.q + |q|^2
+// (a disc's record holds its centre: oc = eye - centre is formed here).
 __device__ __forceinline__ double hit_any64_from(int type, const double* R, const double o[3], const double q[3],
                                                  const double d[3]) {
   if (type == SRH_PRIM_SPHERE) {
@@ -218,7 +221,8 @@ __device__ __forceinline__ double hit_any64_from(int type, const double* R, cons
   const double t = (R[3] - dot3(R, q)) / dot3(R, d);
   if (type == SRH_PRIM_PLANE) return t;
   if (type == SRH_PRIM_DISK) {
-    const double qx = (R[4] + q[0]) + t * d[0], qy = (R[5] + q[1]) + t * d[1], qz = (R[6] + q[2]) + t * d[2];
+    const double qx = ((o[0] - R[4]) + q[0]) + t * d[0], qy = ((o[1] - R[5]) + q[1]) + t * d[1],
+                 qz = ((o[2] - R[6]) + q[2]) + t * d[2];
     return ((qx * qx + qy * qy) + qz * qz <= R[7]) ? t : __builtin_inf();
   }
   const double p[3] = {(o[0] + q[0]) + t * d[0], (o[1] + q[1]) + t * d[1], (o[2] + q[2]) + t * d[2]};

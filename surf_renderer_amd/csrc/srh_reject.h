@@ -47,6 +47,10 @@ __device__ __host__ inline PixelBasis pixel_basis(const FrameDev& F) {
   return B;
 }
 
+__device__ inline double abs_dot3(const double* a, const double* b) {
+  return fabs(a[0] * b[0]) + fabs(a[1] * b[1]) + fabs(a[2] * b[2]);
+}
+
 __device__ inline void rec_zero(float* out, int n) {
   for (int i = 0; i < n; ++i) out[i] = 0.0f;
 }
@@ -70,7 +74,11 @@ __device__ inline void plane_estimate_record(const double n[3], double k, const 
                                              float* hi_u) {
   const double a = dot3(n, B.D0), b = dot3(n, B.Dc), c = dot3(n, B.Dr);
   const double sg = (k > 0.0) ? 1.0 : ((k < 0.0) ? -1.0 : 0.0);
-  const double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H);
+  // fp64 side: a, b, c carry 2^-52 of the ABSOLUTE terms they were summed from, and so does the n^.d the exact path
+  // divides k by (hit_*64) -- where the plane is seen edge-on over the whole image these exceed 2^-21 of the values
+  // themselves, so the slack also holds 2^-48 of the absolute terms (32x the rounding of either side)
+  const double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H) +
+                   3.552713678800501e-15 * (abs_dot3(n, B.D0) + abs_dot3(n, B.Dc) * W + abs_dot3(n, B.Dr) * H);
   const double K = fabs(k) * (1.0 - 9.5367431640625e-7);
   const double big = (fabs(a) + e + fabs(b) * W + fabs(c) * H) / K, lo = 1025.0 * e / K;
   *unused = 0.0f;
@@ -154,8 +162,12 @@ __device__ inline double conic_record(double T00, double T01, double T02, double
 
 // Upper bound of 1 / t for every hit inside the ball of radius r around the point at eye-relative position -oc:
 // t >= |oc| - r (the ball's nearest point).  1e30 ("no estimate") when the eye is inside or on the ball.
+// fp64 side: |oc| - r cancels when the eye is close to the ball's surface relative to its size, and the exact path's
+// own distance (q = oc + t d against r^2, or the sphere's root -b - sqrt(b^2 - 4 a c)) is then off by up to
+// 2^-24 (|oc| + r) (square root of 2^-51 of the squared terms): the bound gives up 2^-22 (|oc| + r), four times that.
 __device__ inline float ball_inverse_depth_bound(const double oc[3], double r) {
-  const double tmin = sqrt(dot3(oc, oc)) - r;
+  const double l = sqrt(dot3(oc, oc));
+  const double tmin = (l - r) - 2.384185791015625e-7 * (l + fabs(r));
   if (!(tmin > 0.0) || !isfinite(tmin)) return 1.0e30f;
   const double inv = (1.0 + 9.5367431640625e-7) / tmin;
   return (inv < 1.0e30) ? (float)inv * 1.0000002f : 1.0e30f;
@@ -171,9 +183,6 @@ __device__ inline float ball_inverse_depth_bound(const double oc[3], double r) {
 // seed 2002.)  Not trusted -> the record stays "always a candidate".
 __device__ inline bool conic_trusted(double tmax, double emax) {
   return isfinite(emax) && tmax * 16777216.0 > emax;
-}
-__device__ inline double abs_dot3(const double* a, const double* b) {
-  return fabs(a[0] * b[0]) + fabs(a[1] * b[1]) + fabs(a[2] * b[2]);
 }
 
 // sphere silhouette  cq (Pi.Pj) - (oc.Pi)(oc.Pj)  with the trust test; `sq` = magnitude of the terms cq was formed from
@@ -199,13 +208,19 @@ __device__ inline void sphere_conic_record(const double oc[3], double cq, double
 }
 
 // disc: | oc (n.D) + k D |^2 <= r^2 (n.D)^2   (numpy/renderer.py:69,85-88 with t = k / (n.D))
-__device__ inline void disk_reject_record(const double* R, const PixelBasis& B, int W, int H, float* out) {
+__device__ inline void disk_reject_record(const double* R, const double o[3], const PixelBasis& B, int W, int H,
+                                          float* out) {
   const double* n = R;
   const double k = R[3];
-  const double* oc = R + 4;
+  const double oc[3] = {o[0] - R[4], o[1] - R[5], o[2] - R[6]};
   const double r2 = R[7];
   const double* P[3] = {B.D0, B.Dc, B.Dr};
-  double nu[3], u[3][3], mu[3], au[3], is[3];   // mu: |terms of u| summed over the components, au: |u| (L1)
+  // mu: |terms of u| summed over the components, au: |u| (L1).  The exact path forms q = (eye + t d) - c
+  // (hit_disk64, the reference's order): its eye + t d carries 2^-53 (|eye| + |t d|), which in the units of u = q (n.D)
+  // is |eye| |n.P| + |k| |P| -- so |eye| joins the terms, and a camera 1e10 away from the origin makes the record
+  // untrusted instead of wrong
+  double nu[3], u[3][3], mu[3], au[3], is[3];
+  const double ol1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
   for (int j = 0; j < 3; ++j) {
     nu[j] = dot3(n, P[j]);
     mu[j] = au[j] = 0.0;
@@ -216,6 +231,7 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
       mu[j] += fabs(oc[a] * nu[j]) + fabs(k * P[j][a]);
       au[j] += fabs(u[j][a]);
     }
+    mu[j] += ol1 * fabs(nu[j]);
   }
   double t[6], tmax = 0.0, emax = 0.0;
   {
@@ -235,7 +251,7 @@ __device__ inline void disk_reject_record(const double* R, const PixelBasis& B, 
     // Every hit lies on the disc, hence inside the sphere around its centre with its radius, and that sphere's
     // silhouette is a robust, well-conditioned ellipse.  Rare (|cos| < 2e-3), so the extra work is off the common path.
     const double oo = dot3(oc, oc);
-    sphere_conic_record(oc, oo - r2, oo + fabs(r2), P, W, H, out);
+    sphere_conic_record(oc, oo - r2, oo + fabs(r2) + 2.0 * sqrt(dot3(o, o) * oo), P, W, H, out);
   }
   plane_estimate_record(n, k, B, W, H, out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
   // A stand-in shape passes pixels the disc does not cover, and the plane-distance estimate means nothing there:
@@ -290,6 +306,16 @@ __device__ inline void sphere_reject_record(const double* R, const PixelBasis& B
 
 // triangle: for a valid hit (t >= near > 0) sign(n.D) = sign(k), so edge i is satisfied iff
 // sign(k) * (s_i n + k m_i) . D >= 0 with m_i = n x e_i, s_i = (o - v_i) . m_i   (numpy/renderer.py:114-126)
+//
+// fp64 side.  E_i(D) = sg (s_i n + k m_i) . D is a scalar triple product expanded, and it cancels when vertices lie far
+// away on two axes (terms |o - v| |e| ~ 1e40 for a result ~ 1e20): the coefficients computed here, and the value
+// dot(cross(e_i, p - v_i), n^) the exact path computes per pixel, then both differ from E_i by rounding noise that has
+// nothing to do with the fp32 margin.  Both are bounded through the ABSOLUTE terms: with am_j = |n_a e_b| + |n_b e_a|
+// (terms of m_j), as = sum_j (|o_j| + |v_j|) am_j (terms of s) and Dsum >= every |D_j| of the image,
+//   |computed E_i - E_i|,  |exact path's value * (n^.D) - E_i|   <=   2^-48 (2 as + |k| sum_j am_j) Dsum  =: err
+// (32x the 2^-53 of each rounding; the exact path's own terms are the same ones: its p - v_i carries
+// 2^-53 (|o| + |v| + |t d|), its n^.d another 2^-51, which multiplies s_i).  `err`, in pixels after the
+// normalisation, is added to the edge's margin; an edge whose noise reaches a quarter pixel stays "always a candidate".
 __device__ inline void triangle_reject_record(const double* R, const double o[3], const PixelBasis& B, int W, int H,
                                               bool near_positive, float* out) {
   rec_zero(out, 16);
@@ -299,20 +325,27 @@ __device__ inline void triangle_reject_record(const double* R, const double o[3]
   plane_estimate_record(n, k, B, W, H, out + 3, out + 7, out + 11, out + 12, out + 13, out + 14);
   if (!near_positive) return;
   const double sg = (k > 0.0) ? 1.0 : ((k < 0.0) ? -1.0 : 0.0);
+  double dsum = 0.0;
+  for (int j = 0; j < 3; ++j) dsum += fabs(B.D0[j]) + fabs(B.Dc[j]) * W + fabs(B.Dr[j]) * H;
   for (int i = 0; i < 3; ++i) {
     const double* v = R + 4 + 3 * i;
     const double* e = R + 13 + 3 * i;
     const double m[3] = {n[1] * e[2] - n[2] * e[1], n[2] * e[0] - n[0] * e[2], n[0] * e[1] - n[1] * e[0]};
+    const double am[3] = {fabs(n[1] * e[2]) + fabs(n[2] * e[1]), fabs(n[2] * e[0]) + fabs(n[0] * e[2]),
+                          fabs(n[0] * e[1]) + fabs(n[1] * e[0])};
     const double ov[3] = {o[0] - v[0], o[1] - v[1], o[2] - v[2]};
     const double s = dot3(ov, m);
+    const double as = (fabs(o[0]) + fabs(v[0])) * am[0] + (fabs(o[1]) + fabs(v[1])) * am[1] + (fabs(o[2]) + fabs(v[2])) * am[2];
     const double w[3] = {sg * (s * n[0] + k * m[0]), sg * (s * n[1] + k * m[1]), sg * (s * n[2] + k * m[2])};
     double a = dot3(w, B.Dc), b = dot3(w, B.Dr), g = dot3(w, B.D0);
     const double len = sqrt(a * a + b * b);
     if (!(len > 0.0) || !isfinite(len) || !isfinite(g)) continue;
+    const double err = 3.552713678800501e-15 * (2.0 * as + fabs(k) * (am[0] + am[1] + am[2])) * dsum / len;   // pixels
+    if (!(err < 0.25)) continue;
     a /= len; b /= len; g /= len;                             // signed distance to the edge line, pixels
     if (!(fabs(g) < 1.0e9)) continue;
     // fp32 evaluation of a*c + b*r + g with rounded a, b, g: error < 3 * 2^-24 (|g| + W + H); margin 2.7x that
-    g += 0.000244140625 + 4.76837158203125e-7 * (fabs(g) + W + H);
+    g += 0.000244140625 + 4.76837158203125e-7 * (fabs(g) + W + H) + err;
     out[4 * i + 0] = (float)a;
     out[4 * i + 1] = (float)b;
     out[4 * i + 2] = (float)g;

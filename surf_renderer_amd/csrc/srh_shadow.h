@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
       const int tile = inside ? ((int)lr / kTile) * LF.tiles_x + (int)lc / kTile : 0;
       for (int sg = 0; sg < F.nseg; ++sg) {
         const uint32_t* big = LF.large + LF.seg[sg].first;
-        const uint32_t nbig = LF.counters[sg];
+        const uint32_t nbig = large_length(LF, sg);
         for (uint32_t i = 0; i < nbig; ++i) test(sg, (int)big[i]);
         if (inside) {
           const int bin = sg * LF.ntiles_pad + tile;

@@ -644,6 +644,23 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     return out
 
 
+def _source_leaves(scene: Dict[str, Any]) -> Dict[str, Any]:
+    """The caller's own leaf objects under the keys flatten_scene files them under."""
+    out: Dict[str, Any] = {}
+    for kind, grp in scene["objects"].items():
+        for name in _OBJ_FIELDS.get(kind, ()):
+            if name in grp:
+                out[f"{kind}.{name}"] = grp[name]
+    out["lights.pos"] = scene["lights"]["pos"]
+    out["colors"] = scene["colors"]
+    out["materials.albedo"] = scene["materials"]["albedo"]
+    for key, (grp, name) in {"lights.attenuation": ("lights", "attenuation"), "lights.ambient": ("lights", "ambient"),
+                             "materials.coeffs": ("materials", "coeffs")}.items():
+        if name in scene[grp]:
+            out[key] = scene[grp][name]
+    return out
+
+
 class ResidentScene:
     """A scene flattened ONCE and rendered many times -- the shape of an optimisation loop
     (diffrend/torch/test_optimization.py: render, loss, backward, optimiser step, repeat).  ``render(scene)`` pays the
@@ -672,6 +689,20 @@ class ResidentScene:
         self.shade = (shading, bool(double_sided), bool(use_quartic), False)
         self.inputs = [self.buf.tensors[k] for k in _float_keys(self.buf, shading)]
         self.differentiable = any(t.requires_grad for t in self.inputs)
+        # "In place" has to be true for every leaf that is being optimised: a float64, CPU or non-contiguous leaf is
+        # COPIED once by flatten_scene (the copy stays attached to autograd, so its gradients still reach the leaf and
+        # the optimiser keeps stepping it) -- and every later render() would draw the first iteration's values.
+        stale = []
+        for key, leaf in _source_leaves(scene).items():
+            if isinstance(leaf, torch.Tensor) and leaf.requires_grad and key in self.buf.tensors:
+                t = self.buf.tensors[key]
+                if t.data_ptr() != leaf.data_ptr() or t.dtype != leaf.dtype or t.device != leaf.device:
+                    stale.append(f"{key} ({str(leaf.dtype).replace('torch.', '')} on {leaf.device}"
+                                 f"{'' if leaf.is_contiguous() else ', not contiguous'})")
+        if stale:
+            raise ValueError("ResidentScene uses differentiable leaves in place, and these would be copied once and "
+                             "then never refreshed: " + ", ".join(stale) + f".  Give contiguous float32 tensors on "
+                             f"{self.device}, or call render(scene) per iteration (it converts on every call).")
 
     def set_camera(self, camera: Dict[str, Any]) -> None:
         self._camera = camera

@@ -298,3 +298,30 @@ def test_resident_scene_matches_render_and_sees_in_place_updates():
     c = rs.render()
     d = render(scene, device="cuda:0")
     assert torch.equal(c["image"], d["image"]) and not torch.equal(c["image"], a["image"])
+
+
+@pytest.mark.parametrize("how", ["float64", "cpu", "strided"])
+def test_resident_scene_refuses_leaves_it_would_have_to_copy(how):
+    """A differentiable leaf that is float64, on the CPU or not contiguous cannot be used in place: flatten_scene would
+    copy it once, the optimiser would keep stepping the leaf, and every later render() would draw the first iteration's
+    values.  ResidentScene says so instead of going stale; render(scene), which converts per call, still takes it."""
+    import torch
+    from surf_renderer_amd import ResidentScene, render, synthetic
+    scene = synthetic.demo_scene(48, 40, with_planes=True)
+    base = np.asarray(scene["objects"]["disk"]["pos"], dtype=np.float32)
+    if how == "float64":
+        pos = torch.tensor(base.astype(np.float64), device="cuda:0", requires_grad=True)
+    elif how == "cpu":
+        pos = torch.tensor(base, requires_grad=True)
+    else:
+        wide = torch.zeros((base.shape[0], 8), device="cuda:0")
+        wide[:, :4] = torch.tensor(base, device="cuda:0")
+        pos = wide[:, :4].detach().requires_grad_(True)
+        assert not pos.is_contiguous()
+    scene["objects"]["disk"] = dict(scene["objects"]["disk"], pos=pos)
+    with pytest.raises(ValueError, match="disk.pos"):
+        ResidentScene(scene, device="cuda:0")
+    res = render(scene, device="cuda:0")
+    (res["image"] ** 2).sum().backward()
+    assert pos.grad is not None and bool(torch.isfinite(pos.grad).all())
+

@@ -36,6 +36,18 @@ def test_oracle_matches_reference_output(case, tile):
     np.testing.assert_allclose(got["image"], want["image"], rtol=1e-12, atol=1e-14, equal_nan=True)
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_ordered_dot_variant_matches_reference_output(case):
+    """`dots="ordered"` (the four np.dot products as explicit sums in a fixed order, what the GPU path is compared with
+    where results hang on the last bit) is pinned by the same reference outputs, to the same tolerance."""
+    scene, want, _ = load_case(os.path.join(GOLDEN_DIR, case + ".npz"))
+    got = np_oracle.render(scene, dots="ordered")
+    np.testing.assert_array_equal(got["nearest"], want["nearest"])
+    np.testing.assert_array_equal(np.isfinite(got["depth"]), np.isfinite(want["depth"]))
+    np.testing.assert_allclose(got["depth"], want["depth"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got["image"], want["image"], rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
 def test_oracle_row_window_equals_full_frame():
     scene, want, _ = load_case(os.path.join(GOLDEN_DIR, "g2_demo_planes_64x48.npz"))
     part = np_oracle.render(scene, rows=(10, 23))
