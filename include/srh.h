@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SRH_ABI_VERSION 9
+#define SRH_ABI_VERSION 10
 #define SRH_MAX_SEGMENTS 4
 #define SRH_MAX_LIGHTS 64
 
@@ -149,10 +149,18 @@ typedef struct SrhParams {
                                    from the bins a SRH_STAGE_BIN call with the same arguments left in the workspace.
                                    Lets a caller run the latency-bound binning of frame i+1 on one stream beside the
                                    render kernel of frame i on another (surf_renderer_amd/pipeline.py) */
-  int32_t reserved0;
+  int32_t counters_clean;       /* binned frames: 1 = the caller KNOWS that this workspace's bin counters are zero, so the
+                                   frame needs no clearing launch: the workspace's last use was a binned frame of the SAME
+                                   (objects, width, height) whose render stage ran without SRH_STAGE_KEEP_BINS (the render
+                                   kernel leaves every counter it read at zero), and nothing else wrote to it since.
+                                   0 = unknown (a fresh or re-purposed workspace): the library clears them first.  Wrong
+                                   claims cannot make the kernels leave the workspace (every list access is bounded by
+                                   the list's capacity) but give a wrong image. */
 } SrhParams;
 
-enum { SRH_STAGE_BIN = 1, SRH_STAGE_RENDER = 2 };
+/* SrhParams.stages.  SRH_STAGE_KEEP_BINS (with SRH_STAGE_RENDER): the render kernel leaves the bin counters as they are,
+ * so the same bins can be rendered again (measurement builds); the workspace is then NOT clean afterwards. */
+enum { SRH_STAGE_BIN = 1, SRH_STAGE_RENDER = 2, SRH_STAGE_KEEP_BINS = 4 };
 
 int srh_abi_version(void);
 const char* srh_last_error(void);

@@ -100,7 +100,10 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
   const SegDev& S = F.seg[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S.count) return;
+  // which set of frame-wide list lengths this frame counts into (srh_device.h: kLargeNext); stable for the whole binning
+  const uint32_t set = F.tilerange ? (F.counters[kLargeNext] & 1u) : 0u;
   if (s == 0 && i == 0) {
+    if (F.tilerange) F.counters[kLargeNow] = set;          // ... and the render kernel reads the same one
     // per-frame fp64 copy of the lights for the fragment stage: position, colour looked up through color_idx
     double* L = const_cast<double*>(F.lights64);
     for (int l = 0; l < F.nlights; ++l) {
@@ -160,9 +163,9 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
       }
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
     }
-    const TileBox box = bin_primitive(F, s, TYPE, Q, S.first + i, near_eye);
+    const TileBox box = bin_primitive(F, s, TYPE, Q, S.first + i, set, near_eye);
 #if SRH_FUSE_BIN
-    if (box.tx0 <= box.tx1) bin_place<1>(F, s, TYPE, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1);
+    if (box.tx0 <= box.tx1) bin_place<1>(F, s, TYPE, S.first, Q, S.first + i, 0, box.tx0, box.ty0, box.tx1, box.ty1, set);
 #else
     (void)box;
 #endif
@@ -817,15 +820,22 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   // and tile bins into the workspace, SRH_STAGE_RENDER = the render kernel from bins a previous SRH_STAGE_BIN call with
   // the same arguments left there.  0 = both.
   const int stages = params->stages == 0 ? (SRH_STAGE_BIN | SRH_STAGE_RENDER) : params->stages;
-  if (stages & ~(SRH_STAGE_BIN | SRH_STAGE_RENDER)) return fail(SRH_E_TYPE, "unknown stages mask %d", params->stages);
-  if (stages != (SRH_STAGE_BIN | SRH_STAGE_RENDER) && mode != SRH_MODE_BINNED)
+  if (stages & ~(SRH_STAGE_BIN | SRH_STAGE_RENDER | SRH_STAGE_KEEP_BINS)) return fail(SRH_E_TYPE, "unknown stages mask %d", params->stages);
+  if ((stages & (SRH_STAGE_BIN | SRH_STAGE_RENDER)) != (SRH_STAGE_BIN | SRH_STAGE_RENDER) && mode != SRH_MODE_BINNED)
     return fail(SRH_E_TYPE, "SrhParams.stages splits binned frames only");
   const bool abl_skip_binning = !(stages & SRH_STAGE_BIN), abl_skip_render = !(stages & SRH_STAGE_RENDER);
   if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
-  if (mode == SRH_MODE_BINNED && !abl_skip_binning) {
-    // The bin counters start every frame at zero.  A kernel, not hipMemsetAsync: captured into a hipGraph and replayed
-    // beside a live RCCL process group the memset NODE did not take effect and the counters grew from frame to frame
-    //  -- a kernel node has the same ordering as its neighbours by construction.
+  F.keep_bins = (stages & SRH_STAGE_KEEP_BINS) ? 1 : 0;
+#ifdef SRH_ALWAYS_ZERO      // measurement build: the clearing launch of every frame, as before ABI 10
+  const bool counters_clean = false;
+#else
+  const bool counters_clean = params->counters_clean != 0;
+#endif
+  if (mode == SRH_MODE_BINNED && !abl_skip_binning && !counters_clean) {
+    // The bin counters start every frame at zero.  The render kernel leaves them that way (render_binned_body), so
+    // a workspace that goes from frame to frame needs this launch only the first time (SrhParams.counters_clean).
+    // A kernel, not hipMemsetAsync: captured into a hipGraph and replayed beside a live RCCL process group a memset
+    // NODE did not take effect.
     const size_t ncount = (size_t)kCounterPad + (size_t)F.nbins;
     hipLaunchKernelGGL(k_zero_counters, dim3((unsigned)((ncount + 1023) / 1024)), dim3(256), 0, st, F.counters, (uint32_t)ncount);
   }
@@ -1015,7 +1025,8 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   const FrameDev& F0 = stage[0];
   const unsigned V = (unsigned)n_views;
   const size_t ncount = (size_t)kCounterPad + (size_t)F0.nbins;
-  hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
+  if (!params->counters_clean)               // as in srh_render_fwd: every view's render kernel leaves its counters at zero
+    hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, Fs);
   for (int s = 0; s < F0.nseg; ++s)
     launch_prep_views(F0, Fs, s, V, st);
 #if !SRH_FUSE_BIN

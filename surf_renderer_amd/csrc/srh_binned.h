@@ -33,7 +33,7 @@ __device__ __forceinline__ int segment_of(const FrameDev& F, int gidx) {
 struct TileBox { int tx0, ty0, tx1, ty1; };        // inclusive; tx0 > tx1: not binned (no pixel, or on the large list)
 
 __device__ inline TileBox bin_primitive(const FrameDev& F, int seg, int type, const float* rec32, int gidx,
-                                        bool force_large = false) {
+                                        uint32_t set, bool force_large = false) {
   BBox b = bbox_full();
   if (force_large) { /* keep the full box */ }
   else if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) b = conic_bbox(rec32);
@@ -54,7 +54,7 @@ __device__ inline TileBox bin_primitive(const FrameDev& F, int seg, int type, co
   if (is_large) {                                                 // the batch's region of `large` starts at seg.first
     // bounded like the bin lists: whatever the counter holds (a workspace whose counters were never cleared), the
     // store stays inside the batch's region -- every primitive joins at most once, so a clean counter never exceeds it
-    const uint32_t slot = atomicAdd(&F.counters[seg], 1u);
+    const uint32_t slot = atomicAdd(&F.counters[4u * set + seg], 1u);
     if (slot < (uint32_t)F.seg[seg].count) F.large[F.seg[seg].first + slot] = (uint32_t)gidx;
     return TileBox{1, 0, 0, 0};
   }
@@ -98,7 +98,7 @@ constexpr int kCountLanes = SRH_COUNT_LANES;
 constexpr int kClaims = SRH_BIN_CLAIMS;
 template <int kLanes>
 __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, int first, const float* rec32, int gidx,
-                                          int sub, int tx0, int ty0, int tx1, int ty1) {
+                                          int sub, int tx0, int ty0, int tx1, int ty1, uint32_t set) {
   uint32_t* count = F.counters + kCounterPad + seg * F.ntiles_pad;
   const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
   const RectTest T(type, rec32, F.near_clip > 0.0);
@@ -143,7 +143,7 @@ __device__ __forceinline__ void bin_place(const FrameDev& F, int seg, int type, 
 #pragma unroll
   for (int m = 1; m < kLanes; m <<= 1) over |= __shfl_xor(over, m);
   if (sub == 0 && over) {
-    const uint32_t at = atomicAdd(&F.counters[seg], 1u);
+    const uint32_t at = atomicAdd(&F.counters[4u * set + seg], 1u);
     if (at < (uint32_t)F.seg[seg].count) F.large[first + at] = (uint32_t)gidx;
   }
 }
@@ -162,7 +162,7 @@ __device__ __forceinline__ void bin_count_body(const FrameDev& F) {
   for (int i = 1; i < SRH_MAX_SEGMENTS; ++i)
     if (seg == i) { type = F.seg[i].type; first = F.seg[i].first; base = F.seg[i].rec32; }
   const float* rec32 = base + (size_t)(gidx - first) * rec32_stride(type);
-  bin_place<kCountLanes>(F, seg, type, first, rec32, gidx, sub, tx0, ty0, tx1, ty1);
+  bin_place<kCountLanes>(F, seg, type, first, rec32, gidx, sub, tx0, ty0, tx1, ty1, F.counters[kLargeNext] & 1u);
 }
 
 // the bin's list and its length (bin = seg * ntiles_pad + tile)
@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t bin_length(const FrameDev& F, int bin) {
 
 // length of batch s's frame-wide list, clamped to the batch like bin_length to the bin: reads stay inside the workspace
 __device__ __forceinline__ uint32_t large_length(const FrameDev& F, int s) {
-  return min(F.counters[s], (uint32_t)F.seg[s].count);
+  return min(F.counters[4u * (F.counters[kLargeNow] & 1u) + s], (uint32_t)F.seg[s].count);
 }
 
 __global__ __launch_bounds__(kBinBlock) void k_bin_count(FrameDev F) { bin_count_body(F); }
@@ -1139,6 +1139,22 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 #else
         if (nearest) nearest[row * F.near_stride + c] = besti;
 #endif
+      }
+    }
+  }
+  // Leave the counters as the next frame's binning needs them: zero -- a frame is then prep-and-bin + render, without a
+  // clearing launch in front (SrhParams.counters_clean).  A tile's own bin counters were read by nobody else.  The
+  // frame-wide list lengths are read by every tile until the kernel ends: tile 0 zeroes the OTHER set and makes it the
+  // next frame's (kLargeNext; a ticket that finds the last tile to finish was measured first: 16 384 returning atomics
+  // on one word made the frame 0.115 ms instead of 0.078).
+  if (!F.keep_bins) {
+    if (WPT > 1) __syncthreads();             // the four waves of the tile have all finished reading
+    if ((WPT == 1 || wave == 0) && lane == 0) {
+      for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) F.counters[kCounterPad + s * F.ntiles_pad + tile] = 0u;
+      if (tile == 0) {
+        const uint32_t other = (F.counters[kLargeNow] & 1u) ^ 1u;
+        for (int s = 0; s < SRH_MAX_SEGMENTS; ++s) F.counters[4u * other + s] = 0u;
+        F.counters[kLargeNext] = other;
       }
     }
   }

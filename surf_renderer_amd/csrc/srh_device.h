@@ -20,6 +20,12 @@ constexpr int kTile = 16;                         // binning tile edge in pixels
 constexpr int kMaxTilesPerPrim = 64;              // primitives overlapping more tiles go to the `large` list
 constexpr int kMinBinCap = 16;                    // one-pass binning: smallest capacity of a bin list
 constexpr int kCounterPad = 64;                   // dwords in front of the per-tile counters
+// The frame-wide (`large`) list lengths exist twice, and frames alternate between the two sets: every tile of a frame
+// reads its set until the render kernel ends, so that kernel cannot zero it for the next frame -- but it can zero the
+// OTHER set, which nobody reads any more, and hand it over: word kLargeNext says which set the next frame's binning
+// counts into (flipped by the render kernel), word kLargeNow which set this frame's render kernel reads (copied there
+// by the binning).  All in device memory: a captured frame can be replayed any number of times.
+constexpr int kLargeNext = 8, kLargeNow = 9;
 
 // One scene['objects'] entry as the kernels see it.
 struct SegDev {
@@ -61,14 +67,16 @@ struct FrameDev {
   double slab_ma[3], slab_mg[3], slab_na, slab_ng;
   int32_t slab_cull, pad3;
   uint16_t* tilerange;               // (total,4) tx0,ty0,tx1,ty1 inclusive; tx0 > tx1 = not binned
-  uint32_t* counters;                // [s] n_large of batch s | [64, 64+nbins) bin counts
+  uint32_t* counters;                // [4p + s] n_large of batch s, set p | [8] set of the NEXT frame | [9] set of this frame |
+                                     // [64, 64+nbins) bin counts   (see kLargeNext below)
   uint32_t* large;                   // (total) primitives too big to bin; batch s owns [seg[s].first, +count)
   uint32_t* entries;                 // (nbins, bin_cap) binned global indices: bin b's list starts at b * bin_cap
   // Light views of the shadow pass (srh_shadow.h): bins are queried at CONTINUOUS positions, so a tile's rectangle grows
   // by bin_pad pixels on every side (0 for pixel-centre rendering), and primitives within near_ball of the eye go to
   // the `large` lists (every query tests them).  view_valid = 0: this light has no usable view (all-pairs fallback).
   double bin_pad, near_ball;
-  int32_t view_valid, pad5;
+  int32_t view_valid;
+  int32_t keep_bins;                 // the render kernel leaves the bin counters alone (SRH_STAGE_KEEP_BINS, light views)
   SegDev seg[SRH_MAX_SEGMENTS];
   const double* lights64;            // (nlights,6) per-frame fp64 copy written by k_prep: position xyz, colour rgb
   const float* lpos;

@@ -88,6 +88,10 @@ class FramePipeline:
         if self.use_graphs:
             self._capture(strict_graphs)
 
+    def _note(self, b: int, what: str) -> None:
+        """A graph replay runs no Python: tell the renderer's bookkeeping what it left in scratch b's bin counters."""
+        renderer._ws_note(self.scratch[b], (what, renderer._layout_key(self.buf, self.width, self.height)))
+
     def _render(self, b: int, ev=None, stages: int = 0) -> None:
         image, depth = slab_views(self.slabs[b], self.width)
         renderer.render_buffers(self.buf, self.cam, rows=self.rows, mode=self.mode, out=(image, depth, None),
@@ -107,7 +111,11 @@ class FramePipeline:
         try:
             for b in range(self.n):
                 with torch.cuda.stream(self.streams[0 if self.schedule == "stages" else b % self.n_streams]):
-                    self._render(b)                              # warm: module load, allocator
+                    # warm: module load, allocator -- and the scratch's bin counters: a whole frame leaves them zero, so
+                    # the captured frames need no clearing launch.  The two diagnostic schedules replay one half only:
+                    # they are captured on a scratch that holds bins (render-only renders them again and again; bin-only
+                    # bins over them, so its graph carries the clearing launch).
+                    self._render(b, stages=_lib.STAGE_BIN if self.schedule in ("render-only", "bin-only") else 0)
                 torch.cuda.synchronize(self.device)
                 if self.schedule == "stages":
                     self.bin_graphs[b] = capture(self.streams[0], b, _lib.STAGE_BIN)
@@ -139,6 +147,7 @@ class FramePipeline:
                     sb.wait_event(self._render_done[b])          # this pair's previous frame has been rendered
                 if self.bin_graphs[b] is not None:
                     self.bin_graphs[b].replay()
+                    self._note(b, "binned")
                 else:
                     self._render(b, stages=_lib.STAGE_BIN)
                 self._bin_done[b].record(sb)
@@ -146,6 +155,7 @@ class FramePipeline:
                 sr.wait_event(self._bin_done[b])
                 if self.graphs[b] is not None and ev is None:
                     self.graphs[b].replay()
+                    self._note(b, "clean")
                 else:
                     self._render(b, ev, stages=_lib.STAGE_RENDER)
                 if self._render_done[b] is None:
@@ -161,7 +171,7 @@ class FramePipeline:
         return b
 
     def _half(self) -> int:
-        return {"render-only": _lib.STAGE_RENDER, "bin-only": _lib.STAGE_BIN}.get(self.schedule, 0)
+        return {"render-only": _lib.STAGE_RENDER | _lib.STAGE_KEEP_BINS, "bin-only": _lib.STAGE_BIN}.get(self.schedule, 0)
 
     def sync(self) -> None:
         for s in self.streams:

@@ -336,6 +336,26 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# What a workspace's bin counters hold is known only to whoever used it last, so it is noted ON the tensor object (the
+# note dies with it; a new tensor over recycled memory starts unknown): ("clean", layout) after a binned frame whose
+# render kernel left every counter at zero, ("binned", layout) between a frame's two stages.  A clean workspace needs
+# no clearing launch (SrhParams.counters_clean): a frame is then two kernels.
+def _ws_state(ws: torch.Tensor):
+    return getattr(ws, "_srh_state", None)
+
+
+def _ws_note(ws: torch.Tensor, state) -> None:
+    try:
+        ws._srh_state = state
+    except AttributeError:                                  # a tensor type that takes no attributes: always unknown
+        pass
+
+
+def _layout_key(buf: "SceneBuffers", width: int, height: int, what="frame"):
+    ob = buf.objects
+    return (what, tuple((ob.seg[s].type, ob.seg[s].count) for s in range(ob.n_segments)), int(width), int(height))
+
+
 def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None,
                    mode: str = "auto", out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
                    want_nearest: bool = True, events: Optional[_lib.EventPair] = None,
@@ -383,12 +403,28 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
                             stages=int(stages))
     if workspace is None:
         workspace = buf.ensure_workspace(width, height)
+    binned = mode in ("auto", "binned") and not cam.ortho
+    after = None
+    if binned:
+        key = _layout_key(buf, width, height)
+        halves = int(stages) & (_lib.STAGE_BIN | _lib.STAGE_RENDER) or (_lib.STAGE_BIN | _lib.STAGE_RENDER)
+        state = _ws_state(workspace)
+        if halves & _lib.STAGE_BIN:
+            params.counters_clean = int(state == ("clean", key))
+        elif state != ("binned", key):
+            raise ValueError("stages=STAGE_RENDER needs the bins of a stages=STAGE_BIN call with the same scene and "
+                             "frame size in this workspace (its last use left it " +
+                             ("without any" if state is None else f"{state[0]}") + ")")
+        after = ("binned", key) if (not halves & _lib.STAGE_RENDER or int(stages) & _lib.STAGE_KEEP_BINS) else ("clean", key)
+        _ws_note(workspace, None)                           # unknown until the call has been accepted
     with torch.cuda.device(buf.device):
         rc = lib.srh_render_fwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                 C.byref(params), workspace.data_ptr(), workspace.numel(),
                                 image.data_ptr(), depth.data_ptr(),
                                 nearest.data_ptr() if nearest is not None else None, _stream_ptr(buf.device))
     _lib.check(rc)
+    if binned:
+        _ws_note(workspace, after)
     return image, depth, nearest
 
 
@@ -561,11 +597,18 @@ def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], imag
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=buf.device)
     arr = (_lib.SrhCamera * n)(*cams)
+    binned = not cams[0].ortho
+    key = _layout_key(buf, width, height, ("views", n))
+    if binned:
+        params.counters_clean = int(_ws_state(workspace) == ("clean", key))
+        _ws_note(workspace, None)
     with torch.cuda.device(buf.device):
         _lib.check(lib.srh_render_views(n, arr, C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                         C.byref(params), workspace.data_ptr(), workspace.numel(), images.data_ptr(),
                                         depths.data_ptr(), nearests.data_ptr() if nearests is not None else None,
                                         _stream_ptr(buf.device)))
+    if binned:
+        _ws_note(workspace, ("clean", key))
     return workspace
 
 
