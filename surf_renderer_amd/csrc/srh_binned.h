@@ -392,7 +392,10 @@ struct RejectRecord {
 __device__ __forceinline__ f32x2 splat2(float x) { return f32x2{x, x}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int TYPE, bool PRETEST>
+// SCALE = false leaves out the factor 1 / |D|: the value is then den = inv |D|, which orders the candidates of ONE pixel
+// exactly as inv does -- the typed kernels of planar primitives track their keys in that unit (kDenKeys) and convert at
+// the few places that compare a key with a depth.
+template <int TYPE, bool PRETEST, bool SCALE = true>
 __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f32x2 (&cf)[2], float rf,
                                             const f32x2 (&rlen)[2], int32_t (&sel)[4], f32x2 (&inv)[2]) {
   f32x2 den[2];
@@ -454,16 +457,17 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
   for (int p = 0; p < 2; ++p) {
     if (!PRETEST) inv[p] = splat2(kNoEstimate);
     else if (TYPE == SRH_PRIM_SPHERE) inv[p] = splat2(R[5]);    // per-sphere constant (sphere_reject_record)
-    else inv[p] = den[p] * rlen[p];
+    else if (SCALE) inv[p] = den[p] * rlen[p];
+    else inv[p] = den[p];
   }
 }
 
 // One staged primitive against the lane's four pixels: update the keys.
-template <int TYPE, bool PRETEST>
+template <int TYPE, bool PRETEST, bool DENKEYS>
 __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_t field, QuadState& Q) {
   int32_t sel[4];
   f32x2 inv[2];
-  pair_bounds<TYPE, PRETEST>(R, Q.cf, Q.rf, Q.rlen, sel, inv);
+  pair_bounds<TYPE, PRETEST, !DENKEYS>(R, Q.cf, Q.rf, Q.rlen, sel, inv);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
@@ -565,18 +569,25 @@ __device__ __forceinline__ void stream_list_vec(const SegDev& S, const uint32_t*
   }
 }
 
-template <int TYPE, bool PRETEST, int WPT>
+template <int TYPE, bool PRETEST, int WPT, bool DENKEYS>
 __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
                                            uint32_t ord0, QuadState& Q, uint32_t part, int lane) {
 #if SRH_SWEEP_VEC
   stream_list_vec<TYPE, WPT>(S, list, n_all, ord0, part, lane, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
-    sweep_entry<TYPE, PRETEST>(R, field, Q);
+    sweep_entry<TYPE, PRETEST, DENKEYS>(R, field, Q);
   });
 #else
   stream_list<TYPE, WPT>(S, list, n_all, ord0, part, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
-    sweep_entry<TYPE, PRETEST>(R, field, Q);
+    sweep_entry<TYPE, PRETEST, DENKEYS>(R, field, Q);
   });
 #endif
+}
+
+// Keys of the one-batch kernels of PLANAR primitives hold den = inv |D| instead of inv (see pair_bounds): one packed
+// multiply per entry less, and it is the unit the matrix path produces.  Spheres carry a per-sphere inverse depth, and
+// the all-types kernel mixes them with the others: those keep inv.
+__host__ __device__ constexpr bool den_keys(int batch) {
+  return batch == SRH_PRIM_DISK || batch == SRH_PRIM_TRIANGLE || batch == SRH_PRIM_PLANE;
 }
 
 // Re-sweep, lane-parallel: every lane whose pixel is still undecided (`open`) walks the tile's list again with the
@@ -676,11 +687,12 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
+      constexpr bool DK = den_keys(BATCH);
       switch (BATCH >= 0 ? BATCH : S.type) {
-        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
-        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
-        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
-        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST, WPT>(S, list, n, ord0, Q, part, lane); break;
+        case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT, DK>(S, list, n, ord0, Q, part, lane); break;
+        case SRH_PRIM_PLANE: sweep_list<SRH_PRIM_PLANE, PRETEST, WPT, DK>(S, list, n, ord0, Q, part, lane); break;
+        case SRH_PRIM_SPHERE: sweep_list<SRH_PRIM_SPHERE, PRETEST, WPT, DK>(S, list, n, ord0, Q, part, lane); break;
+        default: sweep_list<SRH_PRIM_TRIANGLE, PRETEST, WPT, DK>(S, list, n, ord0, Q, part, lane); break;
       }
       ord0 += n;
     }
@@ -928,7 +940,8 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
     Q.rf = (float)r;
     // |D|^2 of the quad's four pixels: D(c0 + j) = D(c0) + j Dc, so |D|^2 = A + j (B + j C) with A = |D(c0)|^2,
     // B = 2 D(c0).Dc, C = |Dc|^2 -- one fp64 ray instead of four (equal to ~1e-16 relative; only the fp32 bound uses it)
-    double len2[4];
+    double len2[4] = {1.0, 1.0, 1.0, 1.0};
+    if (!den_keys(BATCH)) {
 #ifdef SRH_ABL_LEN2_EACH
 #pragma unroll
     for (int j = 0; j < 4; ++j) len2[j] = pixel_len2(F, min(c0 + j, F.W - 1), r);
@@ -948,6 +961,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       for (int j = 0; j < 4; ++j) len2[j] = __builtin_fma((double)j, __builtin_fma((double)j, C, 2.0 * B), A);
     }
 #endif
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = min(c0 + j, F.W - 1);
@@ -1075,7 +1089,11 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
         const int32_t sentinel = kKeys == 4 ? p.k4 : p.k3;
         bool saturated = false;
         // a key still "reaches" the confirmed depth iff its inverse-depth bound is >= reach_of(bound)
-        // (one reciprocal per confirmation instead of one per key; 0 while nothing is confirmed)
+        // (one reciprocal per confirmation instead of one per key; 0 while nothing is confirmed).  Keys in den units
+        // (den_keys): den = inv |D|, so the threshold is scaled by |D| -- rounded DOWN (len is the fp32 of the fp64
+        // length; 1 - 2^-21 covers that and the product), clamped again so that a key without an estimate still
+        // reaches everything.
+        const float key_unit = den_keys(BATCH) ? len * 0.9999995f : 1.0f;
         float reach = 0.0f;
 #pragma unroll
         for (int q = 0; q < kKeys - 1; ++q) {
@@ -1090,7 +1108,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
               if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
               else confirm_global<TCH, BATCH>(F, g, d, best, besti);
               bound = float_above(best);
-              reach = reach_of(bound);                  // bound = inf (a miss) gives 0 again
+              reach = fminf(reach_of(bound) * key_unit, kReachMax);   // bound = inf (a miss) gives 0 again
             }
           }
         }

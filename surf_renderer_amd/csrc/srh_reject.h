@@ -58,8 +58,10 @@ __device__ inline void rec_zero(float* out, int n) {
 // Depth-estimate fields of a planar primitive with unit normal n and plane offset k (see the file header):
 //   u_j = w_j / K  with  w0 = s v0 + E, w1 = s v1, w2 = s v2,  s = sign(k),  K = |k| (1 - 2^-20),  and lo_u, hi_u.
 // The kernel evaluates den = u0 + c u1 + r u2 = (s (n^.D) + E) / K up to an fp32 error below E / K, where
-//   E = 2^-21 (|v0| + W |v1| + H |v2|)  covers the three rounded coefficients and the two fmas (2.7x slack),
-// so s (n^.D) / K <= den always.  A valid hit with near > 0 has s (n^.D) > 0 and ray distance
+//   E = 2^-19 (|v0| + W |v1| + H |v2|)  covers the three rounded coefficients and the two fmas of the vector path
+// (5 x 2^-24) and, with 2x slack, the matrix path (sweep_bin_mfma): the constant moved to the tile origin by two more
+// fmas, every coefficient split into three bfloat16 parts (2^-24 of itself left over) and nine exact products summed
+// in fp32 (at most 16 x 2^-24 together) -- so s (n^.D) / K <= den always.  A valid hit with near > 0 has s (n^.D) > 0 and ray distance
 //   t = |k| |D| / (s n^.D) >= |D| / ((1 - 2^-20) max(den, lo_u))      for ANY lo_u > 0
 // (the 2^-20 absorbs the roundings of |D|, the reciprocal and the product).  The kernel uses exactly that,
 //   lower bound = |D| rcp(max(den, lo_u)),   lo_u = 1025 E / K:
@@ -77,7 +79,7 @@ __device__ inline void plane_estimate_record(const double n[3], double k, const 
   // fp64 side: a, b, c carry 2^-52 of the ABSOLUTE terms they were summed from, and so does the n^.d the exact path
   // divides k by (hit_*64) -- where the plane is seen edge-on over the whole image these exceed 2^-21 of the values
   // themselves, so the slack also holds 2^-48 of the absolute terms (32x the rounding of either side)
-  const double e = 4.76837158203125e-7 * (fabs(a) + fabs(b) * W + fabs(c) * H) +
+  const double e = 1.9073486328125e-6 * (fabs(a) + fabs(b) * W + fabs(c) * H) +
                    3.552713678800501e-15 * (abs_dot3(n, B.D0) + abs_dot3(n, B.Dc) * W + abs_dot3(n, B.Dr) * H);
   const double K = fabs(k) * (1.0 - 9.5367431640625e-7);
   const double big = (fabs(a) + e + fabs(b) * W + fabs(c) * H) / K, lo = 1025.0 * e / K;
@@ -94,69 +96,63 @@ __device__ inline void plane_estimate_record(const double n[3], double k, const 
   *hi_u = (float)(-1023.0 * e / K) * 1.0000002f;
 }
 
-// Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4], out[11].
+// Conic x^T T x <= 0, x = (1, c, r)  ->  inflated, normalised ellipse record out[0..4] (out[11] = 0: the quadratic form
+//   dc (A11 dc + 2A12 dr) + A22 dr^2 - 1 <= 0,  dc = c - c0, dr = r - r0).
 // Returns the major semi-axis in pixels, or -1 (record = "always a candidate") when the conic is not a
 // well-conditioned ellipse: not positive definite, centre or size beyond 2^20 pixels, or axis ratio > 512
 // (a disc seen edge-on; its parameters are then numerical noise).
+//
+// ONE form for every ellipse (until round 3 elongated ones were stored in a principal-axes form).  The record is
+// evaluated in two ways, and the inflation `thr` covers both:
+//   vector path   centre-relative in fp32 (pair_bounds, ellipse_reject): three rounded coefficients and five rounded
+//                 operations on terms up to Tm near the boundary;
+//   matrix path   (sweep_bin_mfma) as the polynomial a0 + a1 x + a2 y + a3 x^2 + a4 x y + a5 y^2 in TILE-LOCAL pixel
+//                 coordinates x, y in [0, 15]: coefficients moved to the tile origin in fp32 (six rounded operations),
+//                 each split into two float16 parts (2^-22 of itself left over), twelve exact products summed in fp32.
+//                 Its terms reach the form's value, with absolute values, 15 pixels beyond the tile origin; a binned
+//                 tile starts at most 17 pixels outside the ellipse's box.
+// Tm = A11 X^2 + 2|A12| X Y + A22 Y^2 + 1 with X = hc + 34, Y = hr + 34 (hc, hr = half extents of the box) bounds the
+// sum of the absolute terms of either evaluation; each commits at most 2.6 * 2^-20 Tm, `rel` is 2^-18 Tm.  A point
+// inside the true ellipse has A d.d <= 1, hence value <= 1 / thr - 1 <= -rel / (1 + rel) after the inflation.
 __device__ inline double conic_record(double T00, double T01, double T02, double T11, double T12, double T22,
                                       int W, int H, float* out) {
   rec_zero(out, 5);
-  out[11] = 0.0f;                                              // quadratic form unless set below
+  out[11] = 0.0f;
   const double det = T11 * T22 - T12 * T12;
   if (!(T11 > 0.0) || !(det > 0.0) || !isfinite(T00 + T01 + T02 + T11 + T12 + T22)) return -1.0;
   const double c0 = -(T22 * T01 - T12 * T02) / det;
   const double r0 = -(T11 * T02 - T12 * T01) / det;
   const double F0 = T00 + T01 * c0 + T02 * r0;                 // value at the centre, < 0 inside
   if (!(F0 < 0.0)) return -1.0;
-  double A11 = T11 / -F0, A12 = T12 / -F0, A22 = T22 / -F0;
+  const double iF = -1.0 / F0;
+  const double A11 = T11 * iF, A12 = T12 * iF, A22 = T22 * iF;
   const double mean = 0.5 * (A11 + A22), dev = sqrt(0.25 * (A11 - A22) * (A11 - A22) + A12 * A12);
   const double lmax = mean + dev, lmin = mean - dev;
   if (!(lmin > 0.0) || !isfinite(lmax)) return -1.0;
-  double smin = 1.0 / sqrt(lmax);
+  const double smin = 1.0 / sqrt(lmax);
   const double smax = 1.0 / sqrt(lmin);
   const double far_lim = 1048576.0;
   if (!(fabs(c0) < far_lim) || !(fabs(r0) < far_lim) || !(smax < far_lim)) return -1.0;
   if (!(smax <= 512.0 * smin)) return -1.0;
-  double cond = (smax / smin) * (smax / smin);   // terms of the quadratic form reach cond * Q near the boundary
-  const double pos_err = 2.384185791015625e-7 * (fabs(c0) + fabs(r0) + W + H);   // 2^-22 (...), see below
-  if (smax > 8.0 * smin) {
-    // Elongated ellipse: the quadratic form would cancel in fp32, so the record holds the principal-axes form
-    //   u = ex*dc + ey*dr, v = ex*dr - ey*dc, candidate iff (u*iu)^2 + (v*iv)^2 - 1 <= 0     (out[11] = iv > 0)
-    // (ex, ey) = unit eigenvector of the small eigenvalue = direction of the major axis.
-    double vx = lmin - A22, vy = A12;
-    if (fabs(lmin - A11) > fabs(vx)) { vx = A12; vy = lmin - A11; }
-    const double vl = sqrt(vx * vx + vy * vy);
-    if (vl > 0.0 && isfinite(vl)) {
-      const double ex = vx / vl, ey = vy / vl;
-      // u, v carry the position error (x sqrt 2), the rounding of ex, ey and of the two fmas (< 2^-21 smax);
-      // scaling both semi-axes by 1 + rho/smin covers every point within rho of the ellipse
-      const double rho = 0.000244140625 + 3.0 * pos_err + 9.5367431640625e-7 * smax;
-      const double grow = (1.0 + rho / smin) * (1.0 + 1.9073486328125e-6);
-      out[0] = (float)c0;
-      out[1] = (float)r0;
-      out[2] = (float)ex;
-      out[3] = (float)ey;
-      out[4] = (float)(1.0 / (smax * grow));
-      out[11] = (float)(1.0 / (smin * grow));
-      return smax * grow;
-    }
-    A11 = A22 = 1.0 / (smax * smax);   // no usable axis direction: bounding circle
-    A12 = 0.0;
-    smin = smax;
-    cond = 1.0;
-  }
-  // Margins.  Position: c0, r0 are rounded to fp32 (2^-24 |c0|) and so is c - c0 (2^-24 (W + |c0|)), together
-  // < 2^-23 (|c0| + |r0| + W + H) pixels; delta doubles that and adds 2^-12 px.  Value: three rounded coefficients
-  // and five rounded operations on terms up to cond * Q, < 2^-20 cond relative; `rel` is four times that.
+  const double dA = A11 * A22 - A12 * A12;
+  if (!(dA > 0.0)) return -1.0;
+  const double idA = 1.0 / dA;
+  const double X = sqrt(A22 * idA) + 34.0, Y = sqrt(A11 * idA) + 34.0;
+  const double Tm = A11 * X * X + 2.0 * fabs(A12) * X * Y + A22 * Y * Y + 1.0;
+  // Position: c0, r0 are rounded to fp32 (2^-24 |c0|) and so is c - c0 (2^-24 (W + |c0|)), together
+  // < 2^-23 (|c0| + |r0| + W + H) pixels; delta doubles that and adds 2^-12 px.
+  const double pos_err = 2.384185791015625e-7 * (fabs(c0) + fabs(r0) + W + H);
   const double delta = 0.000244140625 + pos_err;
-  const double rel = 3.814697265625e-6 * cond;
+  const double rel = 3.814697265625e-6 * Tm;
   const double grow = 1.0 + delta / smin;
   const double thr = grow * grow * (1.0 + rel);
+  if (!(thr < 1.0e6)) return -1.0;
+  const double it = 1.0 / thr;
   out[0] = (float)c0;
   out[1] = (float)r0;
-  out[2] = (float)(A11 / thr);
-  out[3] = (float)(2.0 * A12 / thr);
-  out[4] = (float)(A22 / thr);
+  out[2] = (float)(A11 * it);
+  out[3] = (float)(2.0 * A12 * it);
+  out[4] = (float)(A22 * it);
   return smax * sqrt(thr);
 }
 
