@@ -677,8 +677,10 @@ struct TileLists {
   }
 };
 
+// `passes`: bit 0 = the frame-wide lists, bit 1 = the tile's bins (a list that is left out still counts its ordinals)
 template <bool PRETEST, int WPT, int BATCH = -1>
-__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part, int lane) {
+__device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadState& Q, uint32_t part, int lane,
+                                           int passes = 3) {
   const TileLists L{F, tile};
   uint32_t ord0 = 0;
   for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) {
@@ -687,6 +689,7 @@ __device__ __forceinline__ void sweep_tile(const FrameDev& F, int tile, QuadStat
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t* list = L.list(s, pass);
       const uint32_t n = L.count(s, pass);
+      if (!((passes >> pass) & 1)) { ord0 += n; continue; }
       constexpr bool DK = den_keys(BATCH);
       switch (BATCH >= 0 ? BATCH : S.type) {
         case SRH_PRIM_DISK: sweep_list<SRH_PRIM_DISK, PRETEST, WPT, DK>(S, list, n, ord0, Q, part, lane); break;
@@ -789,6 +792,10 @@ __device__ __forceinline__ void resweep_tile(const FrameDev& F, int tile, bool o
 struct alignas(16) Parked {
   int32_t k1, k2, k3, k4;
 };
+
+}  // namespace srh
+#include "srh_mfma.h"
+namespace srh {
 
 // Workgroup -> tiles.  A workgroup renders 4 tiles that are neighbours in x (one per wave).  Workgroups are dealt to
 // the 8 XCDs round-robin by the hardware, and each XCD has its own L2; a primitive overlaps neighbouring tiles, so
@@ -972,13 +979,64 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
       Q.k1[j] = Q.k2[j] = Q.k3[j] = Q.k4[j] = kNoKey;
     }
     const uint32_t part = WPT == 1 ? 0u : (uint32_t)wave;     // which share of the tile's entries this wave sweeps
-    if (pretest) sweep_tile<true, WPT, BATCH>(F, tile, Q, part, lane);
-    else sweep_tile<false, WPT, BATCH>(F, tile, Q, part, lane);
+    // Disc bins go through the matrix cores (srh_mfma.h) unless the tile's lists are too long for an unsaturated key
+    // field; the frame-wide list (huge discs, overflowing bins: usually empty) stays on the vector path, whose
+    // centre-relative evaluation does not care how far the tile is from the ellipse.
+    uint32_t n_wide = 0, n_bin = 0;
+    bool matrix = false;
+    if (SRH_MFMA && BATCH == SRH_PRIM_DISK) {
+      const TileLists L{F, tile};
+      n_wide = L.count(0, 0);
+      n_bin = L.count(0, 1);
+      matrix = n_wide + n_bin + 1u <= kOrdMask;
+    }
+    const int passes = matrix ? (n_wide ? 1 : 0) : 3;
+    if (passes) {
+      if (pretest) sweep_tile<true, WPT, BATCH>(F, tile, Q, part, lane, passes);
+      else sweep_tile<false, WPT, BATCH>(F, tile, Q, part, lane, passes);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Parked p;
       p.k1 = Q.k1[j]; p.k2 = Q.k2[j]; p.k3 = Q.k3[j]; p.k4 = Q.k4[j];
       park[wave][j][lane] = p;
+    }
+    if (SRH_MFMA && BATCH == SRH_PRIM_DISK && matrix && n_bin > part) {
+      int32_t K[8][4];
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) K[g][q] = kNoKey;
+      const TileLists L{F, tile};
+      if (pretest) sweep_bin_mfma<true, WPT>(F.seg[0], L.list(0, 1), n_bin, n_wide, part, lane, px0, py0, K);
+      else sweep_bin_mfma<false, WPT>(F.seg[0], L.list(0, 1), n_bin, n_wide, part, lane, px0, py0, K);
+      mfma_merge_keys<WPT>(lane, K);
+      // both lanes of a pixel now hold its keys: lanes 0-31 file the even groups, lanes 32-63 the odd ones, into the
+      // (row quad, lane) slots of the vector layout, on top of whatever the frame-wide list left there
+      wave_lds_fence();
+      const bool upper = lane >= 32;
+      const int col = lane & 31, x = col & 15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = 2 * (2 * i + (upper ? 1 : 0)) + (col >> 4);
+        Parked& slot = park[wave][x & 3][y * 4 + (x >> 2)];
+        Parked p = slot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int32_t key = upper ? K[2 * i + 1][q] : K[2 * i][q];
+          if (kKeys == 4) p.k4 = imed3(p.k3, key, p.k4);
+          p.k3 = imed3(p.k2, key, p.k3);
+          p.k2 = imed3(p.k1, key, p.k2);
+          p.k1 = max(p.k1, key);
+        }
+        slot = p;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Parked p = park[wave][j][lane];
+        Q.k1[j] = p.k1; Q.k2[j] = p.k2; Q.k3[j] = p.k3; Q.k4[j] = p.k4;
+      }
     }
     if (WPT > 1) {
       // merge: pixel j = wave of every lane collects the keys the four waves found for it
