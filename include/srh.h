@@ -156,7 +156,15 @@ typedef struct SrhParams {
                                    0 = unknown (a fresh or re-purposed workspace): the library clears them first.  Wrong
                                    claims cannot make the kernels leave the workspace (every list access is bounded by
                                    the list's capacity) but give a wrong image. */
+  int32_t per_view;             /* srh_render_views only: SRH_VIEWS_* bits -- which of `objects`, `lights`, `materials` point
+                                   to ARRAYS of n_views structs (one scene per view) instead of one struct for all views.
+                                   Every view's objects must have the same batches (types and counts) as view 0's. */
+  int32_t reserved1;
 } SrhParams;
+
+/* SrhParams.per_view: the reference's real batch loop changes geometry, eye and light per element
+ * (diffrend/torch/GAN/gan.py:325-378: disk.pos / disk.normal = samples[idx], camera eye, lights.pos[0]) */
+enum { SRH_VIEWS_OBJECTS = 1, SRH_VIEWS_LIGHTS = 2, SRH_VIEWS_MATERIALS = 4 };
 
 /* SrhParams.stages.  SRH_STAGE_KEEP_BINS (with SRH_STAGE_RENDER): the render kernel leaves the bin counters as they are,
  * so the same bins can be rendered again (measurement builds); the workspace is then NOT clean afterwards. */
@@ -216,9 +224,10 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
                    const int32_t* nearest, const float* depth,
                    const SrhGrads* grads, void* stream);
 
-/* Many views of one scene in one call: the batch axis of the reference's real callers, which render one view per
+/* Many views in one call: the batch axis of the reference's real callers, which render one view per
  * render() call in a Python loop (diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  `cameras` is an
- * array of n_views cameras with one viewport size; `params` is shared (binned mode; row range and output row strides as
+ * array of n_views cameras with one viewport size; objects / lights / materials are one scene for all views or, per
+ * SrhParams.per_view, one per view (same batch structure); `params` is shared (binned mode; row range and output row strides as
  * in srh_render_fwd, so a multi-GPU rank can render its slab of a whole batch of frames); the outputs are stacked:
  * view v starts v * rows * row_stride elements after view 0 in images (n_views,rows,W,3), depths (n_views,rows,W)
  * and nearests (may be NULL).  Every kernel of the

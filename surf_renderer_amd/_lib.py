@@ -55,9 +55,11 @@ class SrhParams(C.Structure):
                 ("image_row_stride", C.c_int64), ("depth_row_stride", C.c_int64),
                 ("nearest_row_stride", C.c_int64),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("visibility", C.c_void_p),
-                ("view_row0", C.c_void_p), ("stages", C.c_int32), ("counters_clean", C.c_int32)]
+                ("view_row0", C.c_void_p), ("stages", C.c_int32), ("counters_clean", C.c_int32),
+                ("per_view", C.c_int32), ("reserved1", C.c_int32)]
 
 STAGE_BIN, STAGE_RENDER, STAGE_KEEP_BINS = 1, 2, 4
+VIEWS_OBJECTS, VIEWS_LIGHTS, VIEWS_MATERIALS = 1, 2, 4
 
 
 class SrhGrads(C.Structure):

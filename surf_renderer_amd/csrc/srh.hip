@@ -471,17 +471,7 @@ __global__ __launch_bounds__(256) void k_render_fast(FrameDev F, float* __restri
         const float dr = rf - Q[1];
         float q[P];
         float m = __builtin_inff();
-        if (Q[11] > 0.0f) {                    // elongated ellipse: principal-axes form (srh_reject.h)
-          const float eydr = Q[3] * dr, exdr = Q[2] * dr;
-#pragma unroll
-          for (int j = 0; j < P; ++j) {
-            const float dc = cf[j] - Q[0];
-            const float u = __builtin_fmaf(Q[2], dc, eydr) * Q[4];
-            const float v = __builtin_fmaf(-Q[3], dc, exdr) * Q[11];
-            q[j] = __builtin_fmaf(u, u, __builtin_fmaf(v, v, -1.0f));
-            m = fminf(m, q[j]);
-          }
-        } else {
+        {
           const float e = Q[3] * dr;
           const float g = __builtin_fmaf(Q[4] * dr, dr, -1.0f);
 #pragma unroll
@@ -937,6 +927,26 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
   const int W = cameras[0].viewport[2] - cameras[0].viewport[0], H = cameras[0].viewport[3] - cameras[0].viewport[1];
   const size_t one = srh_workspace_bytes(objects, W, H);
   if (!one) return SRH_E_RANGE;               // srh_workspace_bytes left the message
+  if (params->per_view & ~(SRH_VIEWS_OBJECTS | SRH_VIEWS_LIGHTS | SRH_VIEWS_MATERIALS))
+    return fail(SRH_E_TYPE, "unknown per_view mask %d", params->per_view);
+  if (!lights || !materials) return fail(SRH_E_NULL, "lights / materials is NULL");
+  // view v's scene: the shared structs, or element v of the arrays SrhParams.per_view names
+  auto objects_of = [&](int v) { return (params->per_view & SRH_VIEWS_OBJECTS) ? objects + v : objects; };
+  auto lights_of = [&](int v) { return (params->per_view & SRH_VIEWS_LIGHTS) ? lights + v : lights; };
+  auto materials_of = [&](int v) { return (params->per_view & SRH_VIEWS_MATERIALS) ? materials + v : materials; };
+  if (params->per_view & SRH_VIEWS_OBJECTS)
+    for (int v = 1; v < n_views; ++v) {     // one workspace layout, one kernel instantiation and one grid for the whole batch
+      if (objects[v].n_segments != objects[0].n_segments)
+        return fail(SRH_E_RANGE, "view %d has %d object batches, view 0 has %d", v, objects[v].n_segments, objects[0].n_segments);
+      for (int s = 0; s < objects[0].n_segments; ++s)
+        if (objects[v].seg[s].type != objects[0].seg[s].type || objects[v].seg[s].count != objects[0].seg[s].count)
+          return fail(SRH_E_RANGE, "view %d, batch %d: type %d x %d, view 0 has type %d x %d", v, s, objects[v].seg[s].type,
+                      objects[v].seg[s].count, objects[0].seg[s].type, objects[0].seg[s].count);
+    }
+  if (params->per_view & SRH_VIEWS_LIGHTS)
+    for (int v = 1; v < n_views; ++v)
+      if (lights[v].n_lights != lights[0].n_lights)
+        return fail(SRH_E_RANGE, "view %d has %d lights, view 0 has %d", v, lights[v].n_lights, lights[0].n_lights);
   const size_t head = views_header_bytes(n_views);
   if (workspace_bytes < head + (size_t)n_views * one)
     return fail(SRH_E_RANGE, "workspace holds %zu bytes, %d views need %zu", workspace_bytes, n_views,
@@ -957,7 +967,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
       WsLayout Lo;
       SrhParams pv = *params;
       if (params->view_row0) { pv.row0 = params->view_row0[v]; pv.row1 = pv.row0 + (params->row1 - params->row0); }
-      int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, wso + head + (size_t)v * one, one, &F, &Lo);
+      int rc = setup_frame(&cameras[v], objects_of(v), lights_of(v), materials_of(v), &pv, wso + head + (size_t)v * one, one, &F, &Lo);
       if (rc) return rc;
       for (int s = 0; s < F.nseg; ++s) {
         launch_prep(F, s, st);
@@ -1010,7 +1020,7 @@ int srh_render_views(int32_t n_views, const SrhCamera* cameras, const SrhObjects
       pv.row0 = params->view_row0[v];
       pv.row1 = pv.row0 + (params->row1 - params->row0);
     }
-    int rc = setup_frame(&cameras[v], objects, lights, materials, &pv, ws + head + (size_t)v * one, one, &F, &L);
+    int rc = setup_frame(&cameras[v], objects_of(v), lights_of(v), materials_of(v), &pv, ws + head + (size_t)v * one, one, &F, &L);
     if (rc) return rc;
     if (F.ortho) return fail(SRH_E_CAMERA, "view %d is orthographic, view 0 perspective: one projection per call", v);
     setup_binning(F, L, ws + head + (size_t)v * one);

@@ -403,18 +403,9 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
     // candidate iff q <= 0; tested as q - 2^-22 < 0 (a superset) so that the sign bit decides
     const float dr = rf - R[1];
     f32x2 q[2];
-    // principal-axes form iff R[11] > 0 (conic_record stores 0 or a positive finite scale there): compared on the bit
-    // pattern, so that the wave-uniform branch is a scalar compare and not a v_cmp plus mask arithmetic per entry
-    if (__float_as_int(R[11]) > 0) {
-      const float eydr = R[3] * dr, exdr = R[2] * dr;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const f32x2 dc = cf[p] - splat2(R[0]);
-        const f32x2 u = fma2(splat2(R[2]), dc, splat2(eydr)) * splat2(R[4]);
-        const f32x2 v = fma2(splat2(-R[3]), dc, splat2(exdr)) * splat2(R[11]);
-        q[p] = fma2(u, u, fma2(v, v, splat2(-1.00000024f)));
-      }
-    } else {
+    // one form for every ellipse (conic_record; until round 3 elongated ones came in a principal-axes form, chosen
+    // per entry by a wave-uniform branch)
+    {
       const float ee = R[3] * dr;
       const float gg = __builtin_fmaf(R[4] * dr, dr, -1.00000024f);
 #pragma unroll

@@ -13,11 +13,9 @@
 // direction is affine in them:  D(c, r) = D0 + c*Dc + r*Dr   (numpy/renderer.py:152-164).
 //
 // rec32 layouts (floats)
-//   disc (12)      [0] c0 [1] r0 [2] A11 [3] 2*A12 [4] A22 [11] 0 : candidate iff
+//   disc (12)      [0] c0 [1] r0 [2] A11 [3] 2*A12 [4] A22 [8], [11] 0 : candidate iff
 //                  dc*(A11*dc + 2A12*dr) + A22*dr*dr - 1 <= 0,  dc = c - c0, dr = r - r0
 //                  (A = 0: "always a candidate" -- the disc's image is not an ellipse, etc.)
-//                  elongated ellipses use [2] ex [3] ey [4] iu [11] iv > 0: candidate iff
-//                  (u*iu)^2 + (v*iv)^2 - 1 <= 0,  u = ex*dc + ey*dr, v = ex*dr - ey*dc
 //                  [5..7] u0 u1 u2 [9] lo_u [10] hi_u : depth estimate, see plane_estimate_record
 //   sphere (12)    [0..4] as the disc; [5] upper bound of 1 / t for the whole sphere (1e30: none)
 //   triangle (16)  {a_i, b_i, g_i} at [4i..4i+2], i < 3: candidate iff min_i(a_i*c + b_i*r + g_i) >= 0
@@ -358,23 +356,12 @@ template <int N>
 __device__ __forceinline__ void ellipse_reject(const float* __restrict__ R, const float (&cf)[N], float rf,
                                                float (&q)[N]) {
   const float dr = rf - R[1];
-  if (__float_as_int(R[11]) > 0) {                        // principal-axes form (wave-uniform: a scalar compare on the bits)
-    const float eydr = R[3] * dr, exdr = R[2] * dr;
+  const float ee = R[3] * dr;
+  const float gg = __builtin_fmaf(R[4] * dr, dr, -1.0f);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float dc = cf[j] - R[0];
-      const float u = __builtin_fmaf(R[2], dc, eydr) * R[4];
-      const float v = __builtin_fmaf(-R[3], dc, exdr) * R[11];
-      q[j] = __builtin_fmaf(u, u, __builtin_fmaf(v, v, -1.0f));
-    }
-  } else {
-    const float ee = R[3] * dr;
-    const float gg = __builtin_fmaf(R[4] * dr, dr, -1.0f);
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float dc = cf[j] - R[0];
-      q[j] = __builtin_fmaf(dc, __builtin_fmaf(R[2], dc, ee), gg);
-    }
+  for (int j = 0; j < N; ++j) {
+    const float dc = cf[j] - R[0];
+    q[j] = __builtin_fmaf(dc, __builtin_fmaf(R[2], dc, ee), gg);
   }
 }
 
@@ -388,13 +375,6 @@ __device__ inline BBox bbox_full() { return BBox{0, 0, 0, 0, true}; }
 
 // Box of the stored ellipse record (either form), one pixel of slack.
 __device__ inline BBox conic_bbox(const float* rec) {
-  if (rec[11] > 0.0f) {
-    const double ex = rec[2], ey = rec[3], a = 1.0 / (double)rec[4], b = 1.0 / (double)rec[11];
-    const double hc = sqrt(ex * ex * a * a + ey * ey * b * b), hr = sqrt(ey * ey * a * a + ex * ex * b * b);
-    if (!isfinite(hc) || !isfinite(hr)) return bbox_full();
-    return BBox{(double)rec[0] - hc - 1.0, (double)rec[0] + hc + 1.0, (double)rec[1] - hr - 1.0,
-                (double)rec[1] + hr + 1.0, false};
-  }
   const double A11 = rec[2], A12 = 0.5 * (double)rec[3], A22 = rec[4];
   const double det = A11 * A22 - A12 * A12;
   if (!(A11 > 0.0) || !(det > 0.0)) return bbox_full();
@@ -446,14 +426,7 @@ struct RectTest {
       u0 = rec[3]; u1 = rec[7]; u2 = rec[11]; hi = rec[14];
       behind = near_positive;
     } else if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) {
-      if (rec[11] > 0.0f) {                                    // principal-axes form -> quadratic form
-        const double ex = rec[2], ey = rec[3], iu2 = (double)rec[4] * rec[4], iv2 = (double)rec[11] * rec[11];
-        A11 = ex * ex * iu2 + ey * ey * iv2;
-        A12 = ex * ey * (iu2 - iv2);
-        A22 = ey * ey * iu2 + ex * ex * iv2;
-      } else {
-        A11 = rec[2]; A12 = 0.5 * (double)rec[3]; A22 = rec[4];
-      }
+      A11 = rec[2]; A12 = 0.5 * (double)rec[3]; A22 = rec[4];
       ellipse = (A11 > 0.0) && (A22 > 0.0);                    // else "always a candidate"
       i11 = ellipse ? 1.0 / A11 : 0.0;
       i22 = ellipse ? 1.0 / A22 : 0.0;

@@ -6,7 +6,7 @@ queue (`save_to_file`, :36-53; queue and process set-up, :165-179), so PNG encod
 conversions (image -> uint8(255 x); depth: background -> minimum, then 8-bit min-max normalisation), a `None` sentinel
 to stop.  Device tensors are brought to the host through pinned memory with an asynchronous copy; the queue carries
 float32 ndarrays.  The writer process imports numpy only (spawned, like the reference's, so it never inherits a GPU
-context).
+context; the package's own names are imported lazily, so importing this module does not pull in torch).
 
     with FrameWriter(out_dir) as w:
         for i, cam in enumerate(cameras):
@@ -133,14 +133,25 @@ class FrameWriter:
         self.submitted += 1
 
     def close(self, timeout: Optional[float] = None) -> None:
+        """Send the sentinel, wait for the writer to drain the queue and end.  A writer that has died is reported, not
+        waited for (the sentinel goes through the same full-queue / liveness loop as `put`); one that is still running
+        after `timeout` seconds is terminated and reported."""
         if self._proc is None:
             return
-        self._queue.put(None)
-        self._proc.join(timeout)
-        code = self._proc.exitcode
-        self._proc = None
-        if code != 0:
-            raise RuntimeError(f"the writer process ended with exit code {code}")
+        proc, self._proc = self._proc, None
+        while proc.is_alive():
+            try:
+                self._queue.put(None, timeout=1.0)
+                break
+            except queue_mod.Full:
+                continue
+        proc.join(timeout)
+        if proc.is_alive():
+            proc.terminate()
+            proc.join(5.0)
+            raise RuntimeError(f"the writer process did not finish within {timeout} s and was terminated")
+        if proc.exitcode != 0:
+            raise RuntimeError(f"the writer process ended with exit code {proc.exitcode}")
 
     def __enter__(self) -> "FrameWriter":
         return self
@@ -159,7 +170,10 @@ def render_views_to_files(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any
     with FrameWriter(out_dir, queue_size=queue_size) as writer:
         for i in range(0, len(cameras), max(1, int(batch))):
             cams = list(cameras[i:i + batch])
-            res = render_views(scene, cams, want_nearest=False, **render_kw)
+            kw = dict(render_kw)
+            if kw.get("overrides") is not None:               # per-view scenes travel with their cameras
+                kw["overrides"] = list(kw["overrides"][i:i + batch])
+            res = render_views(scene, cams, want_nearest=False, **kw)
             image, depth = _to_host(res["image"]), _to_host(res["depth"])
             for v, cam in enumerate(cams):
                 far = cam["far"]

@@ -137,6 +137,17 @@ class SceneBuffers:
             self.workspace_frame = (w, h)
         return self.workspace
 
+    def ensure_shadow_workspace(self, width: int, height: int) -> torch.Tensor:
+        """Scratch of the accelerated shadow pass: room for the light views (tile bins in every light's screen space)
+        behind the primary frame's scratch."""
+        lib = _lib.load()
+        need = lib.srh_shadow_workspace_bytes(C.byref(self.objects), width, height, self.lights.n_lights)
+        if need == 0:
+            raise _lib.SrhError(-2, lib.srh_last_error().decode())
+        if self.shadow_workspace is None or self.shadow_workspace.numel() < need:
+            self.shadow_workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.shadow_workspace
+
     def new_workspace(self, width: int, height: int) -> torch.Tensor:
         """An additional scratch buffer (one per frame in flight when frames are pipelined over several streams)."""
         lib = _lib.load()
@@ -474,13 +485,7 @@ def shadow_pass(buf: SceneBuffers, cam: _lib.SrhCamera, rows, image: torch.Tenso
     if all_pairs:
         workspace = buf.ensure_workspace(width, height)
     else:
-        # room for the light views (tile bins in every light's screen space) behind the primary frame's scratch
-        need = lib.srh_shadow_workspace_bytes(C.byref(buf.objects), width, height, buf.lights.n_lights)
-        if need == 0:
-            raise _lib.SrhError(-2, lib.srh_last_error().decode())
-        if buf.shadow_workspace is None or buf.shadow_workspace.numel() < need:
-            buf.shadow_workspace = torch.empty(need, dtype=torch.uint8, device=buf.device)
-        workspace = buf.shadow_workspace
+        workspace = buf.ensure_shadow_workspace(width, height)
     with torch.cuda.device(buf.device):
         _lib.check(lib.srh_shadow_shade(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
                                         C.byref(params), workspace.data_ptr(), workspace.numel(), nearest.data_ptr(),
@@ -564,15 +569,65 @@ class _RenderFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads.get(k) for k in keys)
 
 
+_OVERRIDE_FIELDS = {"lights.pos": ("lights", "pos"), "lights.color_idx": ("lights", "color_idx"),
+                    "colors": ("lights", "colors"), "lights.attenuation": ("lights", "attenuation"),
+                    "lights.ambient": ("lights", "ambient"), "materials.albedo": ("materials", "albedo"),
+                    "materials.coeffs": ("materials", "coeffs")}
+
+
+class ViewScenes:
+    """One scene per view, as srh_render_views takes it (SrhParams.per_view): arrays of SrhObjects / SrhLights /
+    SrhMaterials that equal the base scene's except for the pointers a view overrides.  ``overrides[v]`` maps flat leaf
+    names (``"disk.pos"``, ``"disk.normal"``, ``"lights.pos"``, ``"colors"``, ``"materials.albedo"``, ...: the keys of
+    ``SceneBuffers.tensors``) to arrays or tensors of the base leaf's shape -- what the reference's batch loop assigns
+    per element before each ``render()`` (diffrend/torch/GAN/gan.py:325-378: ``disk.pos``, ``disk.normal``,
+    ``lights.pos``).  float32 contiguous tensors on the device are used in place; everything else is converted."""
+
+    def __init__(self, buf: SceneBuffers, overrides: Sequence[Dict[str, Any]]):
+        n = len(overrides)
+        self.n, self.mask, self.keep = n, 0, []
+        self.objects = (_lib.SrhObjects * n)(*[_lib.SrhObjects.from_buffer_copy(buf.objects) for _ in range(n)])
+        self.lights = (_lib.SrhLights * n)(*[_lib.SrhLights.from_buffer_copy(buf.lights) for _ in range(n)])
+        self.materials = (_lib.SrhMaterials * n)(*[_lib.SrhMaterials.from_buffer_copy(buf.materials) for _ in range(n)])
+        for v, ov in enumerate(overrides):
+            for key, val in (ov or {}).items():
+                base = buf.tensors.get(key)
+                if base is None:
+                    raise KeyError(f"view {v}: {key!r} is not a leaf of this scene (leaves: {sorted(buf.tensors)})")
+                t = _as_tensor(val, base.dtype, buf.device)
+                if not t.is_cuda:
+                    t = t.to(buf.device)
+                t = t.reshape(base.shape) if t.numel() == base.numel() else t
+                if tuple(t.shape) != tuple(base.shape):
+                    raise ValueError(f"view {v}: {key} has shape {tuple(t.shape)}, the scene's leaf {tuple(base.shape)}")
+                self.keep.append(t)
+                if key in _OVERRIDE_FIELDS:
+                    which, field = _OVERRIDE_FIELDS[key]
+                    setattr((self.lights if which == "lights" else self.materials)[v], field, t.data_ptr())
+                    self.mask |= _lib.VIEWS_LIGHTS if which == "lights" else _lib.VIEWS_MATERIALS
+                else:
+                    kind, field = key.split(".")
+                    setattr(self.objects[v].seg[buf.kinds.index(kind)], field, t.data_ptr())
+                    self.mask |= _lib.VIEWS_OBJECTS
+
+    def view(self, buf: SceneBuffers, v: int) -> SceneBuffers:
+        """The scene of view v as resident buffers of its own (for the per-view passes: shadows)."""
+        import copy
+        one = copy.copy(buf)
+        one.objects, one.lights, one.materials = self.objects[v], self.lights[v], self.materials[v]
+        return one
+
+
 def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], images: torch.Tensor, depths: torch.Tensor,
                          nearests: Optional[torch.Tensor] = None, rows: Optional[Tuple[int, int]] = None,
                          workspace: Optional[torch.Tensor] = None, image_row_stride: int = 0,
                          depth_row_stride: int = 0, view_row0: Optional[Sequence[int]] = None,
-                         **shading_kw) -> torch.Tensor:
+                         scenes: Optional[ViewScenes] = None, **shading_kw) -> torch.Tensor:
     """Low-level form of ``render_views``: resident scene buffers, camera structs, caller-provided stacked outputs
     (view v starts v * rows * row_stride elements after view 0) and an optional row slab; with ``view_row0`` view v
-    renders rows [view_row0[v], view_row0[v] + rows[1] - rows[0]) instead.  One library call, every pipeline kernel
-    launched once for the whole batch.  Returns the workspace (pass it back in to reuse it)."""
+    renders rows [view_row0[v], view_row0[v] + rows[1] - rows[0]) instead; ``scenes`` gives every view its own
+    geometry / lights / materials (``ViewScenes``).  One library call, every pipeline kernel launched once for the
+    whole batch.  Returns the workspace (pass it back in to reuse it)."""
     lib = _lib.load()
     width, height = frame_size(cams[0])
     r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
@@ -602,8 +657,19 @@ def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], imag
     if binned:
         params.counters_clean = int(_ws_state(workspace) == ("clean", key))
         _ws_note(workspace, None)
+    ob, ls, ms = C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials)
+    if scenes is not None:
+        if scenes.n != n:
+            raise ValueError(f"{scenes.n} per-view scenes for {n} cameras")
+        params.per_view = scenes.mask
+        if scenes.mask & _lib.VIEWS_OBJECTS:
+            ob = scenes.objects
+        if scenes.mask & _lib.VIEWS_LIGHTS:
+            ls = scenes.lights
+        if scenes.mask & _lib.VIEWS_MATERIALS:
+            ms = scenes.materials
     with torch.cuda.device(buf.device):
-        _lib.check(lib.srh_render_views(n, arr, C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+        _lib.check(lib.srh_render_views(n, arr, ob, ls, ms,
                                         C.byref(params), workspace.data_ptr(), workspace.numel(), images.data_ptr(),
                                         depths.data_ptr(), nearests.data_ptr() if nearests is not None else None,
                                         _stream_ptr(buf.device)))
@@ -613,23 +679,26 @@ def render_views_buffers(buf: SceneBuffers, cams: Sequence[_lib.SrhCamera], imag
 
 
 def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], device="cuda", mode: str = "auto",
-                 streams: int = 4, want_nearest: bool = True, batch: int = 256, **shading_kw) -> Dict[str, torch.Tensor]:
-    """Many cameras, one scene: the batch axis of the reference's real callers (one ``render()`` per view in a
-    Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once.  In the
-    default binned mode the views go to the library ``batch`` at a time (``srh_render_views``): every kernel of the
-    frame pipeline is launched once per batch with the view as a grid dimension, so small views neither pay three
-    launches each nor leave the GPU idle.  Other modes, or ``batch=0``, issue one call per view round-robin over
-    ``streams`` HIP streams.  All
-    cameras must share one viewport size.  Returns stacked tensors ``image`` (B,H,W,3), ``depth`` (B,H,W) and
-    ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` / ``use_quartic`` as in ``render``.  Forward only."""
-    unknown = set(shading_kw) - {"shading", "double_sided", "use_quartic", "waves_per_tile"}
-    if "shadow" in unknown and shading_kw["shadow"]:
-        raise ValueError("render_views does not run the shadow-ray pass; call render(scene, shading='torch', "
-                         "shadow=True) per view")
-    unknown.discard("shadow")
+                 streams: int = 4, want_nearest: bool = True, batch: int = 256,
+                 overrides: Optional[Sequence[Dict[str, Any]]] = None, **shading_kw) -> Dict[str, torch.Tensor]:
+    """Many views per call: the batch axis of the reference's real callers (one ``render()`` per view in a
+    Python loop, diffrend/torch/GAN/gan.py:325-378, torch/batch_render.py:36-53).  The scene is uploaded once;
+    ``overrides[v]`` replaces leaves of it for view v (``{"disk.pos": ..., "disk.normal": ..., "lights.pos": ...}``: what
+    the GAN's loop assigns per batch element -- see ``ViewScenes``), so a batch may hold a different splat set and light
+    per view.  In the default binned mode the views go to the library ``batch`` at a time (``srh_render_views``): every
+    kernel of the frame pipeline is launched once per batch with the view as a grid dimension, so small views neither
+    pay three launches each nor leave the GPU idle.  Other modes, or ``batch=0``, issue one call per view round-robin
+    over ``streams`` HIP streams.  All cameras must share one viewport size.  ``shadow=True`` (with ``shading='torch'``)
+    runs the shadow-ray pass on every view after its batch (torch/batch_render.py:59,104-106 renders that way by
+    default); ``visibility`` (B,H,W) int64 is then returned too.  Returns stacked tensors ``image`` (B,H,W,3), ``depth``
+    (B,H,W) and ``nearest`` (B,H,W) int32; ``shading`` / ``double_sided`` / ``use_quartic`` as in ``render``.
+    Forward only."""
+    unknown = set(shading_kw) - {"shading", "double_sided", "use_quartic", "waves_per_tile", "shadow"}
     if unknown:
         raise TypeError(f"render_views() got unexpected keyword arguments {sorted(unknown)}")
-    shading_kw.pop("shadow", None)
+    shadow = bool(shading_kw.pop("shadow", False))
+    if shadow and shading_kw.get("shading", "numpy") != "torch":
+        raise ValueError("shadow rays exist only in the torch backend's semantics: shading='torch'")
     device = torch.device(device)
     buf = flatten_scene(scene, device)
     cams = [camera_struct(c, shading_kw.get("shading", "numpy")) for c in cameras]
@@ -639,12 +708,38 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     if any(frame_size(c) != (width, height) for c in cams):
         raise ValueError("all cameras of a batch must have the same viewport size")
     n = len(cams)
+    if overrides is not None and len(overrides) != n:
+        raise ValueError(f"{len(overrides)} overrides for {n} cameras")
+    want_nearest = want_nearest or shadow                   # the shadow pass starts from the winners
     image = torch.empty((n, height, width, 3), dtype=torch.float32, device=device)
     depth = torch.empty((n, height, width), dtype=torch.float32, device=device)
     nearest = torch.empty((n, height, width), dtype=torch.int32, device=device) if want_nearest else None
     out = {"image": image, "depth": depth}
     if want_nearest:
         out["nearest"] = nearest
+    every = ViewScenes(buf, overrides) if overrides is not None else None
+
+    def scene_of(v: int) -> SceneBuffers:
+        return every.view(buf, v) if every is not None else buf
+
+    def shadows(first: int, count: int) -> None:
+        if not shadow:
+            return
+        if "visibility" not in out:
+            out["visibility"] = torch.empty((n, height, width), dtype=torch.int64, device=device)
+        buf.ensure_shadow_workspace(width, height)          # the per-view copies below share it
+        for v in range(first, first + count):
+            out["visibility"][v] = shadow_pass(scene_of(v), cams[v], None, image[v], depth[v], nearest[v],
+                                               double_sided=bool(shading_kw.get("double_sided", False)),
+                                               use_quartic=bool(shading_kw.get("use_quartic", False)))
+
+    if every is not None and not (mode in ("auto", "binned") and int(batch) > 0):
+        # per-view scenes outside the batched call: one frame per view from that view's buffers
+        for v in range(n):
+            render_buffers(scene_of(v), cams[v], mode=mode, out=(image[v], depth[v], nearest[v] if want_nearest else None),
+                           **shading_kw)
+        shadows(0, n)
+        return out
     if mode in ("auto", "binned") and int(batch) > 0:
         lib = _lib.load()
         shading = shading_kw.get("shading", "numpy")
@@ -663,10 +758,21 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
             for i in range(0, n, step):
                 m = min(step, n - i)
                 arr = (_lib.SrhCamera * m)(*cams[i:i + m])
-                _lib.check(lib.srh_render_views(m, arr, C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                ob, ls, ms = C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials)
+                params.per_view = 0
+                if every is not None:                       # element i of each per-view array is this batch's view 0
+                    params.per_view = every.mask
+                    if every.mask & _lib.VIEWS_OBJECTS:
+                        ob = C.byref(every.objects[i])
+                    if every.mask & _lib.VIEWS_LIGHTS:
+                        ls = C.byref(every.lights[i])
+                    if every.mask & _lib.VIEWS_MATERIALS:
+                        ms = C.byref(every.materials[i])
+                _lib.check(lib.srh_render_views(m, arr, ob, ls, ms,
                                                 C.byref(params), workspace.data_ptr(), workspace.numel(),
                                                 image[i].data_ptr(), depth[i].data_ptr(),
                                                 nearest[i].data_ptr() if want_nearest else None, _stream_ptr(device)))
+                shadows(i, m)
         return out
     n_streams = max(1, min(int(streams), n))
     pool = [torch.cuda.Stream(device) for _ in range(n_streams)]
@@ -684,6 +790,7 @@ def render_views(scene: Dict[str, Any], cameras: Sequence[Dict[str, Any]], devic
     for t in (image, depth, nearest, *scratch, *buf.tensors.values()):
         if t is not None:
             t.record_stream(current)
+    shadows(0, n)
     return out
 
 

@@ -49,7 +49,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.SrhObjects) == 8 + _lib.MAX_SEGMENTS * C.sizeof(_lib.SrhSegment)
     assert C.sizeof(_lib.SrhLights) == 8 + 5 * 8
     assert C.sizeof(_lib.SrhMaterials) == 24
-    assert C.sizeof(_lib.SrhParams) == 16 + 8 + 16 + 2 * 8 + 3 * 8 + 4 * 8 + 8
+    assert C.sizeof(_lib.SrhParams) == 16 + 8 + 16 + 2 * 8 + 3 * 8 + 4 * 8 + 8 + 8        # ... stages, counters_clean | per_view, reserved1
 
 
 def test_workspace_query_validates_its_input(lib):

@@ -76,3 +76,32 @@ def test_rendered_views_reach_the_files(tmp_path):
         im, dz = encode_frame(res["image"].cpu().numpy(), res["depth"].cpu().numpy(), cam["far"])
         np.testing.assert_array_equal(read_png(str(tmp_path / f"img_{i}.png")), im)
         np.testing.assert_array_equal(read_png(str(tmp_path / f"depth_{i}.png")), dz)
+
+
+@pytest.mark.gpu
+def test_shadowed_views_reach_the_files(tmp_path):
+    """batch_render.py renders with shadow=b_shadow, and --shadow defaults to True (:59,104-106,138): the loop on
+    render_views has to do the same."""
+    import torch
+    from surf_renderer_amd import render, synthetic
+    from surf_renderer_amd.frame_writer import render_views_to_files
+    scene = synthetic.demo_scene(56, 40, with_planes=True)
+    rng = np.random.RandomState(4)
+    cams = []
+    for _ in range(4):
+        eye = rng.normal(size=3)
+        eye = 9.0 * eye / np.linalg.norm(eye)
+        cams.append(dict(scene["camera"], eye=[float(eye[0]), abs(float(eye[1])) + 1.0, float(eye[2]), 1.0]))
+    kw = dict(shading="torch", shadow=True)
+    assert render_views_to_files(scene, cams, str(tmp_path), batch=3, device="cuda:0", **kw) == 4
+    lit = 0
+    for i, cam in enumerate(cams):
+        res = render({**scene, "camera": cam}, device="cuda:0", **kw)
+        plain = render({**scene, "camera": cam}, device="cuda:0", shading="torch")
+        torch.cuda.synchronize()
+        lit += int(not torch.equal(res["image"], plain["image"]))
+        im, dz = encode_frame(res["image"].cpu().numpy(), res["depth"].cpu().numpy(), cam["far"])
+        np.testing.assert_array_equal(read_png(str(tmp_path / f"img_{i}.png")), im)
+        np.testing.assert_array_equal(read_png(str(tmp_path / f"depth_{i}.png")), dz)
+    assert lit > 0                                           # the shadow pass changed something
+

@@ -100,6 +100,40 @@ def test_backward_config4_bunny_mesh():
     _check(scene, seed=8, with_depth=False)
 
 
+def test_backward_config4_at_its_own_size():
+    """BASELINE config 4 as named: bunny.obj at 1024 x 1024, d image / d vertex and d image / d normal against the
+    gradient oracle (O(pixels x lights) on the CPU once the forward pass supplies the winners: ~20 s)."""
+    from surf_renderer_amd import synthetic
+    scene = synthetic.bunny_mesh_scene(1024, 1024)
+    got, want = _check(scene, seed=11)
+    assert np.abs(want["triangle.face"][:, 0, :3]).max() > 0 and np.abs(want["triangle.normal"]).max() > 0
+    assert np.all(got["triangle.face"][:, 1:, :] == 0)
+
+
+def test_backward_plane_filling_a_large_frame():
+    """One plane covers every pixel of a 2048 x 1024 frame: all four waves of every workgroup are one run of the same
+    winner (the workgroup-merge path of scatter_primitive_grads, srh_backward.h) and two million per-pixel terms are
+    accumulated into a handful of fp32 sums -- against the fp64 oracle, and twice, for the run-to-run spread of the
+    atomic accumulation order."""
+    f32 = lambda a: np.asarray(a, dtype=np.float32)          # noqa: E731
+    scene = {"camera": {"viewport": [0, 0, 2048, 1024], "fovy": float(np.deg2rad(50.0)), "focal_length": 1.0,
+                        "eye": [0.3, 2.0, 6.0, 1.0], "at": [0.0, 0.0, 0.0, 1.0], "up": [0.0, 1.0, 0.0, 0.0],
+                        "near": 0.1, "far": 1000.0},
+             "lights": {"pos": f32([[3, 6, 5, 1], [-4, 5, 3, 1], [0, 8, -2, 1]]), "color_idx": np.array([1, 2, 3])},
+             "colors": f32([[0, 0, 0], [.8, .5, .4], [.3, .6, .9], [.5, .9, .3]]),
+             "materials": {"albedo": f32([[.7, .6, .5]])},
+             "objects": {"plane": {"pos": f32([[0, 0, -30, 1]]), "normal": f32([[0.05, 0.3, 1.0, 0]]),
+                                   "material_idx": np.array([0])}},
+             "tonemap": {"type": "gamma", "gamma": 0.8}}
+    got, want = _check(scene, seed=5)
+    assert np.abs(want["plane.pos"]).max() > 0 and np.abs(want["plane.normal"]).max() > 0
+    a, _ = _hip_gradients(scene, np.ones((1024, 2048, 3)), None)
+    b, _ = _hip_gradients(scene, np.ones((1024, 2048, 3)), None)
+    for key in a:
+        spread = np.abs(a[key] - b[key]).max()
+        assert spread <= 2e-5 * max(np.abs(a[key]).max(), 1e-30), f"{key}: run-to-run spread {spread}"
+
+
 def test_backward_disk_cloud_and_no_grad_inputs():
     from surf_renderer_amd import render, synthetic
     scene = synthetic.disk_cloud_scene(1500, 160, 120, radius=0.06, seed=3)

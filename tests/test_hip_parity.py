@@ -618,8 +618,12 @@ def test_render_views_refuses_what_it_cannot_do():
     from surf_renderer_amd import render_views, synthetic
     scene = synthetic.demo_scene(32, 24)
     cams = [scene["camera"]]
-    with pytest.raises(ValueError, match="shadow"):
-        render_views(scene, cams, device="cuda:0", shading="torch", shadow=True)
+    with pytest.raises(ValueError, match="shadow"):                              # shadow rays belong to the torch semantics
+        render_views(scene, cams, device="cuda:0", shadow=True)
+    with pytest.raises(KeyError, match="not a leaf"):
+        render_views(scene, cams, device="cuda:0", overrides=[{"disk.colour": np.zeros(3)}])
+    with pytest.raises(ValueError, match="shape"):
+        render_views(scene, cams, device="cuda:0", overrides=[{"lights.pos": np.zeros((7, 4), dtype=np.float32)}])
     with pytest.raises(TypeError, match="unexpected"):
         render_views(scene, cams, device="cuda:0", tile_size=4096)
     with pytest.raises(Exception, match="one projection per call"):           # perspective and orthographic views mixed
@@ -701,3 +705,49 @@ def test_render_views_refuses_stream_capture():
     want, wdep, _ = renderer.render_buffers(buf, cam)
     torch.cuda.synchronize()
     assert torch.equal(img[0], want) and torch.equal(dep[0], wdep)
+
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shading,shadow", [("numpy", False), ("torch", False), ("torch", True)])
+def test_views_with_their_own_geometry_lights_and_shadows(shading, shadow):
+    """The batch loop of the reference's GAN assigns, per element, a new splat set (disk.pos / disk.normal), a new eye and
+    a new position of light 0 before each render() (diffrend/torch/GAN/gan.py:325-378), and batch_render.py renders with
+    shadow=True by default (:59,104-106).  One render_views call with per-view overrides (SrhParams.per_view) gives, view
+    for view, exactly what render() gives for that element's scene -- image, depth, winners, visibility bits."""
+    from surf_renderer_amd import render, render_views, synthetic
+    rng = np.random.RandomState(5)
+    base = synthetic.disk_cloud_scene(900, 96, 80, radius=0.08, seed=3)
+    base["lights"]["attenuation"] = np.array([[1, 0, 0]] * len(base["lights"]["pos"]), dtype=np.float32)
+    n = 5
+    cams, overrides, scenes = [], [], []
+    for v in range(n):
+        e = rng.normal(size=3)
+        e = e / np.linalg.norm(e) * 4.0
+        cams.append(dict(base["camera"], eye=[*map(float, e), 1.0]))
+        pos = np.concatenate([rng.uniform(-1, 1, (900, 3)), np.ones((900, 1))], 1).astype(np.float32)
+        nrm = np.concatenate([rng.normal(size=(900, 3)), np.zeros((900, 1))], 1).astype(np.float32)
+        lpos = np.array(base["lights"]["pos"], dtype=np.float32, copy=True)
+        lpos[0, :3] = rng.uniform(-6, 6, 3)
+        ov = {"disk.pos": torch.tensor(pos, device="cuda:0") if v % 2 else pos, "disk.normal": nrm, "lights.pos": lpos}
+        if v == 3:
+            ov = {"lights.pos": lpos}                       # a view that keeps the base geometry
+        overrides.append(ov)
+        sc = dict(base, camera=cams[v], lights=dict(base["lights"], pos=lpos),
+                  objects={"disk": dict(base["objects"]["disk"], **({"pos": pos, "normal": nrm} if v != 3 else {}))})
+        scenes.append(sc)
+    kw = dict(shading=shading, **({"shadow": True} if shadow else {}))
+    got = render_views(base, cams, device="cuda:0", overrides=overrides, **kw)
+    for batch in (2, 0):                                     # two-view batches; one library call per view
+        again = render_views(base, cams, device="cuda:0", overrides=overrides, batch=batch, **kw)
+        for k in got:
+            assert torch.equal(again[k], got[k]), f"batch={batch}: {k} differs"
+    for v in range(n):
+        one = render(scenes[v], device="cuda:0", **kw)
+        assert torch.equal(got["image"][v], one["image"]), f"view {v}: image"
+        assert torch.equal(got["depth"][v], one["depth"]), f"view {v}: depth"
+        assert torch.equal(got["nearest"][v].to(torch.int64), one["nearest"]), f"view {v}: nearest"
+        if shadow:
+            assert torch.equal(got["visibility"][v], one["light_visibility"]), f"view {v}: visibility"
+    assert not torch.equal(got["image"][0], got["image"][1])
+

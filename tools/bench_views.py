@@ -38,3 +38,35 @@ for i in range(args.calls):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"views {V} streams {S}: {1e6 * dt / (args.calls * V):.1f} us per frame")
+
+# GAN-shaped batch (diffrend/torch/GAN/gan.py:325-378): every view its own splat set and its own light 0 -- one
+# render_views call with per-view overrides against one render() per element
+import numpy as np                                           # noqa: E402
+from surf_renderer_amd import render, render_views          # noqa: E402
+B, M, R = 64, 4096, 128
+rng = np.random.RandomState(0)
+base = synthetic.disk_cloud_scene(M, R, R, radius=0.05, seed=1)
+cams = [dict(base["camera"], eye=[*map(float, 4.0 * e / np.linalg.norm(e)), 1.0]) for e in rng.normal(size=(B, 3))]
+pos = torch.tensor(np.concatenate([rng.uniform(-1, 1, (B, M, 3)), np.ones((B, M, 1))], 2).astype(np.float32), device=dev)
+nrm = torch.tensor(np.concatenate([rng.normal(size=(B, M, 3)), np.zeros((B, M, 1))], 2).astype(np.float32), device=dev)
+lp = torch.tensor(np.asarray(base["lights"]["pos"], dtype=np.float32), device=dev).repeat(B, 1, 1)
+lp[:, 0, :3] = torch.tensor(rng.uniform(-6, 6, (B, 3)).astype(np.float32), device=dev)
+ov = [{"disk.pos": pos[v], "disk.normal": nrm[v], "lights.pos": lp[v]} for v in range(B)]
+
+
+def timed(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+t_batch = timed(lambda: render_views(base, cams, device=dev, overrides=ov, want_nearest=False))
+t_loop = timed(lambda: [render({**base, "camera": cams[v], "lights": dict(base["lights"], pos=lp[v]),
+                                "objects": {"disk": dict(base["objects"]["disk"], pos=pos[v], normal=nrm[v])}}, device=dev)
+                        for v in range(B)], n=3)
+print(f"GAN-shaped batch, {B} views x {R}x{R}, {M} splats each, different per view: render_views {1e3 * t_batch:.2f} ms "
+      f"= {B / t_batch:.0f} views/s; one render() per view {1e3 * t_loop:.2f} ms = {B / t_loop:.0f} views/s")
+
