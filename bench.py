@@ -109,7 +109,10 @@ def parse():
     ap.add_argument("--owner-frac", type=float, default=0.0,
                     help="--slabs owner: the fraction of a frame's rows rendered by the rank that assembles it; "
                          "0 = the others render 128 rows each (0.9375 at 2 ranks, 0.8125 at 4 for 2048 rows)")
-    ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner"],
+    ap.add_argument("--tile-row-cost", type=float, default=10.0,
+                    help="--slabs cost: fixed cost of a tile besides its list entries, in entries (an empty tile still "
+                         "stores its background: measured ~3 us against ~29 us for a median tile of ~90 entries)")
+    ap.add_argument("--slabs", default="auto", choices=["auto", "contiguous", "balanced", "owner", "cost"],
                     help="rows of a rank: one contiguous slab, or (batched collection, H %% 2P == 0) two half-slabs, "
                          "g and P+g of 2P, so that a scene that is densest in the middle loads every rank alike.  "
                          "auto = contiguous: rehearsed with --as-rank, the balanced form evens the ranks out (26-40 us "
@@ -334,6 +337,18 @@ def main():
     if args.as_rank:
         er, ep = (int(t) for t in args.as_rank.split("/"))
         r0, r1 = row_slab(H, er, ep)
+    # --slabs cost: contiguous slabs of equal WORK, from the bin lengths of one probe frame (every rank computes the same
+    # partition from its identical scene replica; nothing is communicated).  Default at 8 ranks: with equal slabs the
+    # middle ranks see twice the candidates of the outer ones and set the pace (profiles/r02_rank_rehearsal.txt).
+    cost_parts = None
+    n_parts = int(args.as_rank.split("/")[1]) if args.as_rank else world
+    if not frames_par and n_parts > 1 and (args.slabs == "cost" or (args.slabs == "auto" and n_parts >= 8)) and \
+            args.mode in ("auto", "binned"):
+        from surf_renderer_amd.dist import cost_weighted_slabs
+        stats = renderer.bin_statistics(buf, cam)
+        cost_parts = cost_weighted_slabs(stats["tile_row_cost"], H, n_parts,
+                                         per_tile_row=args.tile_row_cost * ((W + 15) // 16))
+        r0, r1 = cost_parts[int(args.as_rank.split("/")[0]) if args.as_rank else rank]
     h = r1 - r0
 
     # Framebuffer layout: (rows, 4W) fp32 per slab -- [W x rgb | W x depth] per row -- so one transfer moves both.
@@ -376,7 +391,7 @@ def main():
     pieces = balanced_slabs(H, rank, world) if balanced else [(r0, r1)]
     # owner-weighted slabs (batched collection only): my rows of the frame that rank k assembles differ per k
     owner = batched and not args.as_rank and world > 1 and \
-        (args.slabs == "owner" or (args.slabs == "auto" and world <= 4 and H >= 256 * world))
+        (args.slabs == "owner" or (args.slabs == "auto" and world <= 4 and H >= 256 * world) or cost_parts is not None)
     if owner:
         # pre-flight of the unequal-split exchange; if this stack cannot do it, every rank keeps the equal slabs
         ok = torch.ones(1, device=device)
@@ -397,7 +412,13 @@ def main():
             if rank == 0:
                 print("[bench] unequal-split exchange unavailable: equal slabs", file=sys.stderr)
             owner = False
-    if owner:
+    if owner and cost_parts is not None:
+        rows_all = [cost_parts] * world                # the same work-balanced partition for every frame of a batch
+        my_rows = [rows_all[k][rank] for k in range(world)]
+        send_rows = [b_ - a for a, b_ in my_rows]
+        recv_rows = [b_ - a for a, b_ in rows_all[rank]]
+        pieces = [my_rows[rank]]
+    elif owner:
         owner_frac = args.owner_frac if args.owner_frac > 0 else 1.0 - (world - 1) * min(128, H // (2 * world)) / H
         rows_all = owner_slabs(H, world, owner_frac)
         my_rows = [rows_all[k][rank] for k in range(world)]
@@ -480,12 +501,40 @@ def main():
         batcher = FrameBatcher(world, (0, 4 * W), torch.float32, device, render_slot, before_exchange,
                                after_reuse_wait, n_batches=n_bat, send_rows=send_rows, recv_rows=recv_rows)
         send, recv = batcher.send, batcher.recv
+        # work-balanced slabs are the same rows for every frame of a batch: the rank's slab of all P frames is ONE
+        # library call (srh_render_views), as with equal slabs; frames with timing events still go out one by one
+        one_call = cost_parts is not None and args.batch_call != "off"
+        views_ws = [None] * n_bat
+        pending_evs = []
+
+        def render_batch(first, send_b):
+            st = streams[(first // world) % n_str]
+            b = (first // world) % n_bat
+            img = send_b.as_strided((world, h, W, 3), (h * 4 * W, 4 * W, 3, 1), 0)
+            dep = send_b.as_strided((world, h, W), (h * 4 * W, 4 * W, 1), 3 * W)
+            with torch.cuda.stream(st):
+                views_ws[b] = renderer.render_views_buffers(buf, [cam] * world, img, dep, rows=(0, h),
+                                                            view_row0=[r0] * world, workspace=views_ws[b],
+                                                            image_row_stride=4 * W, depth_row_stride=4 * W)
 
         def step(ev=None):
-            batcher.submit(ev)
             counter[0] += 1
+            if not one_call:
+                batcher.submit(ev)
+                return
+            pending_evs.append(ev)
+            if len(pending_evs) == world:
+                if any(e is not None for e in pending_evs):
+                    for e in pending_evs:
+                        batcher.submit(e)
+                else:
+                    batcher.submit_batch(render_batch)
+                pending_evs.clear()
 
         def fence():
+            for e in pending_evs:                      # a partial last batch goes frame by frame
+                batcher.submit(e)
+            pending_evs.clear()
             batcher.flush()
             torch.cuda.synchronize(device)
             dist.barrier()
@@ -674,7 +723,7 @@ def main():
             enqueue((b,), streams[b], image, depth, scratch[b], ev)
             if not frames_par:
                 with torch.cuda.stream(streams[b]):
-                    pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True)
+                    pending[b] = gather_rows(slabs[b], frames[b], H, dst=0, async_op=True, slabs=cost_parts)
 
         def fence():
             for b in range(n_buf):
@@ -868,7 +917,9 @@ def main():
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
                                     if batched and not owner and args.batch_call != "off" else "per frame"),
-                       "rows_per_rank": (f"owner-weighted: the rank that assembles a frame renders {max(recv_rows)} of "
+                       "rows_per_rank": (f"work-balanced contiguous slabs (bin lengths of a probe frame): "
+                                         f"{[b_ - a for a, b_ in cost_parts]} rows" if cost_parts is not None else
+                                         f"owner-weighted: the rank that assembles a frame renders {max(recv_rows)} of "
                                          f"its {H} rows, the others {min(recv_rows)} each" if owner else
                                          "two half-slabs, g and P+g of 2P" if balanced else "one contiguous slab"),
                        "collection": "none" if (not use_dist or frames_par) else

@@ -253,6 +253,15 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
                      const SrhMaterials* materials, const SrhParams* params, void* workspace, size_t workspace_bytes,
                      const int32_t* nearest, const float* depth, float* image, uint64_t* visibility, void* stream);
 
+/* Measurement helper: where a binned frame's list lengths live in its workspace, so that a caller can count the
+ * (pixel, primitive) tests a frame really executes (bench.py: executed_pair_tests) or weigh image rows by their work
+ * (surf_renderer_amd.dist.cost_weighted_slabs).  After an SRH_STAGE_BIN call for rows [row0, row1), the 32-bit words
+ * at workspace + *offset_bytes hold:  [4 * set + s] length of batch s's frame-wide list, with set = word [9];
+ * [64 + s * *ntiles_pad + ty * *tiles_x + tx] length of the bin of batch s and tile (tx, ty) -- lists longer than
+ * *bin_cap are cut there (their primitives are on the frame-wide list instead).  The render stage zeroes them again. */
+int srh_bin_counters(const SrhObjects* objects, int32_t width, int32_t height, int32_t row0, int32_t row1,
+                     size_t* offset_bytes, int32_t* tiles_x, int32_t* tiles_y, int32_t* ntiles_pad, int32_t* bin_cap);
+
 /* measurement helpers: timing-enabled HIP events usable as SrhParams.ev_start / ev_stop.
  * srh_event_elapsed_ms waits for `stop` to complete (the only call here that blocks the host). */
 int srh_event_create(void** event);

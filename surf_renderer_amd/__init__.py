@@ -9,7 +9,7 @@ this package on the way to its own module and needs numpy only -- not torch and 
 """
 import importlib
 
-_RENDERER = ("render", "render_views", "ResidentScene", "ViewScenes", "flatten_scene", "render_buffers", "camera_struct",
+_RENDERER = ("render", "render_views", "ResidentScene", "CapturedStep", "ViewScenes", "flatten_scene", "render_buffers", "camera_struct",
              "generate_rays")
 _SCENE = ("load_scene", "load_model", "load_obj", "load_splat", "obj_to_triangle_spec")
 

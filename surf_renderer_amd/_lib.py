@@ -71,7 +71,7 @@ class SrhGrads(C.Structure):
 
 EXPORTS = ("srh_abi_version", "srh_last_error", "srh_workspace_bytes", "srh_generate_rays", "srh_render_fwd",
            "srh_render_bwd", "srh_workspace_bytes_views", "srh_render_views", "srh_shadow_shade",
-           "srh_shadow_workspace_bytes",
+           "srh_shadow_workspace_bytes", "srh_bin_counters",
            "srh_event_create", "srh_event_destroy", "srh_event_elapsed_ms")
 
 _lib: Optional[C.CDLL] = None
@@ -130,6 +130,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.srh_shadow_shade.argtypes = [C.POINTER(SrhCamera), C.POINTER(SrhObjects), C.POINTER(SrhLights),
                                      C.POINTER(SrhMaterials), C.POINTER(SrhParams), C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.srh_bin_counters.restype = C.c_int
+    lib.srh_bin_counters.argtypes = [C.POINTER(SrhObjects), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.srh_event_create.restype = C.c_int
     lib.srh_event_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.srh_event_destroy.restype = C.c_int

@@ -1210,6 +1210,21 @@ int srh_render_bwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   return e == hipSuccess ? SRH_OK : hip_fail(e, "backward launch");
 }
 
+int srh_bin_counters(const SrhObjects* objects, int32_t width, int32_t height, int32_t row0, int32_t row1,
+                     size_t* offset_bytes, int32_t* tiles_x, int32_t* tiles_y, int32_t* ntiles_pad, int32_t* bin_cap) {
+  if (!offset_bytes || !tiles_x || !tiles_y || !ntiles_pad || !bin_cap) return fail(SRH_E_NULL, "an output pointer is NULL");
+  if (!srh_workspace_bytes(objects, width, height)) return SRH_E_RANGE;         // validates, leaves the message
+  if (row0 < 0 || row1 > height || row0 >= row1) return fail(SRH_E_RANGE, "row range [%d,%d) outside the %d image rows", row0, row1, height);
+  const WsLayout L = layout_for(objects, width, height);
+  FrameDev F;
+  memset(&F, 0, sizeof(F));
+  F.W = width; F.H = height; F.row0 = row0; F.row1 = row1; F.nseg = objects->n_segments;
+  setup_binning(F, L, nullptr);                        // pointers relative to NULL: only the tile arithmetic is used
+  *offset_bytes = L.counters;
+  *tiles_x = F.tiles_x; *tiles_y = F.tiles_y; *ntiles_pad = F.ntiles_pad; *bin_cap = F.bin_cap;
+  return SRH_OK;
+}
+
 int srh_event_create(void** event) {
   if (!event) return fail(SRH_E_NULL, "event is NULL");
   hipEvent_t ev;

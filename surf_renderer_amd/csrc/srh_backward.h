@@ -438,123 +438,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_BWD_TCH
   const double sgn = F.double_sided ? ((cdotn > 0.0) ? 1.0 : ((cdotn < 0.0) ? -1.0 : 0.0)) : 1.0;
   const int pw = F.use_quartic ? 4 : 2;
 
-  // per-light forward terms, evaluated twice (image first: its value gates the clip / tonemap derivative)
+  // per-light forward terms, evaluated twice (image first: its value gates the clip / tonemap derivative).
+  // The light loops run in fp32: the hit point, the normal and the view direction come out of the fp64 geometry above and
+  // are rounded once; everything a light contributes is then a few dozen fp32 operations whose sums leave as fp32
+  // atomics anyway.  With these terms in fp64 the kernel held 168 registers (three waves per SIMD, 9 of them spilled).
+  const float nf[3] = {(float)n[0], (float)n[1], (float)n[2]};
+  const float cdf[3] = {(float)cdir[0], (float)cdir[1], (float)cdir[2]};
+  const float cdotnf = (float)cdotn, sgnf = (float)sgn;
   struct LightTerms {
-    double lh[3], dist, afac, ldn, nd, rd, cl;
+    float lh[3], dist, afac, ldn, nd, rd, cl;
     bool nz, den_ok;
   };
   auto light_terms = [&](int l, LightTerms& T) {
     const float* lp = F.lpos + 4 * l;
-    const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
-    T.dist = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
-    T.nz = T.dist > 0.0;
-    const double inv = T.nz ? 1.0 / T.dist : 1.0;
+    // the difference is formed in fp64 (light and fragment may be far from the origin and close to each other)
+    const float v[3] = {(float)((double)lp[0] - p[0]), (float)((double)lp[1] - p[1]), (float)((double)lp[2] - p[2])};
+    T.dist = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    T.nz = T.dist > 0.0f;
+    const float inv = T.nz ? 1.0f / T.dist : 1.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) T.lh[k] = v[k] * inv;
-    const double kc = F.latt ? (double)F.latt[3 * l] : 1.0, kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0,
-                 kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
-    const double dp = (pw == 4) ? (T.dist * T.dist) * (T.dist * T.dist) : T.dist * T.dist;
-    const double den = (kc + T.dist * kl) + dp * kq;
-    T.den_ok = fabs(den) > 0.0;
-    T.afac = T.den_ok ? 1.0 / den : 1.0;
-    T.ldn = (T.lh[0] * n[0] + T.lh[1] * n[1]) + T.lh[2] * n[2];
-    T.cl = (cdir[0] * T.lh[0] + cdir[1] * T.lh[1]) + cdir[2] * T.lh[2];
-    T.nd = sgn * (T.afac * T.ldn);
-    T.rd = sgn * (2.0 * T.ldn * cdotn - T.cl);
+    const float kc = F.latt ? F.latt[3 * l] : 1.0f, kl = F.latt ? F.latt[3 * l + 1] : 0.0f, kq = F.latt ? F.latt[3 * l + 2] : 0.0f;
+    const float dp = (pw == 4) ? (T.dist * T.dist) * (T.dist * T.dist) : T.dist * T.dist;
+    const float den = (kc + T.dist * kl) + dp * kq;
+    T.den_ok = fabsf(den) > 0.0f;
+    T.afac = T.den_ok ? 1.0f / den : 1.0f;
+    T.ldn = (T.lh[0] * nf[0] + T.lh[1] * nf[1]) + T.lh[2] * nf[2];
+    T.cl = (cdf[0] * T.lh[0] + cdf[1] * T.lh[1]) + cdf[2] * T.lh[2];
+    T.nd = sgnf * (T.afac * T.ldn);
+    T.rd = sgnf * (2.0f * T.ldn * cdotnf - T.cl);
   };
-  // powers and logarithms in fp32 (a library pow in fp64 alone holds ~60 registers): the forward pass evaluates the
-  // lobe in fp32 too (spec_pow_f32), and the sums these terms enter leave as fp32 atomics
-  auto spec_pow = [&](double rdotc) { return (rdotc == 0.0 && cf[2] == 0.0) ? 1.0 : (double)powf((float)rdotc, (float)cf[2]); };
+  // the forward pass evaluates the lobe in fp32 too (spec_pow_f32)
+  auto spec_pow = [&](float rdotc) { return (rdotc == 0.0f && cf[2] == 0.0f) ? 1.0f : powf(rdotc, cf[2]); };
 
-  double im[3] = {0, 0, 0};
+  float im[3] = {0, 0, 0};
   for (int l = 0; l < F.nlights; ++l) {
     LightTerms T;
     light_terms(l, T);
-    const double w = (cf[0] * fmax(T.nd, 0.0) + cf[1] * spec_pow(fmax(T.rd, 0.0))) * (double)((vis >> l) & 1ull);
+    const float w = (cf[0] * fmaxf(T.nd, 0.0f) + cf[1] * spec_pow(fmaxf(T.rd, 0.0f))) * (float)((vis >> l) & 1ull);
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) im[ch] += w * ((double)F.colors[3 * ci + ch] * alb[ch]) + amb[ch] * alb[ch];
+    for (int ch = 0; ch < 3; ++ch) im[ch] += w * (F.colors[3 * ci + ch] * alb[ch]) + amb[ch] * alb[ch];
   }
-  double g_im[3];
+  float g_im[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    double w = 0.0;
-    if (hit && im[ch] > 0.0) w = F.tonemap ? F.gamma * (double)powf((float)im[ch], (float)(F.gamma - 1.0)) : 1.0;
+    float w = 0.0f;
+    if (hit && im[ch] > 0.0f) w = F.tonemap ? (float)F.gamma * powf(im[ch], (float)(F.gamma - 1.0)) : 1.0f;
     g_im[ch] = g_out[ch] * w;
   }
 
-  double g_n[3] = {0, 0, 0}, g_p[3] = {0, 0, 0};
+  float g_nf[3] = {0, 0, 0}, g_pf[3] = {0, 0, 0};
   float g_alb[3] = {0, 0, 0}, g_cf[3] = {0, 0, 0}, g_amb[3] = {0, 0, 0};     // leave as fp32 atomics: summed in fp32
-  double g_cdir[3] = {0, 0, 0}, g_cdotn = 0.0;
+  float g_cdf[3] = {0, 0, 0}, g_cdotnf = 0.0f;
   for (int l = 0; l < F.nlights; ++l) {
     LightTerms T;
     light_terms(l, T);
-    const double ndotl = fmax(T.nd, 0.0), rdotc = fmax(T.rd, 0.0);
-    const double P = spec_pow(rdotc);
-    const double vl = (double)((vis >> l) & 1ull);
-    const double w = (cf[0] * ndotl + cf[1] * P) * vl;         // the visible light's weight
+    const float ndotl = fmaxf(T.nd, 0.0f), rdotc = fmaxf(T.rd, 0.0f);
+    const float P = spec_pow(rdotc);
+    const float vl = (float)((vis >> l) & 1ull);
+    const float w = (cf[0] * ndotl + cf[1] * P) * vl;          // the visible light's weight
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
-    double g_w = 0.0, g_col[3];
+    float g_w = 0.0f, g_col[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const double col = (double)F.colors[3 * ci + ch];
+      const float col = F.colors[3 * ci + ch];
       g_w += g_im[ch] * col * alb[ch];
-      g_alb[ch] += (float)(g_im[ch] * (w * col + amb[ch]));
+      g_alb[ch] += g_im[ch] * (w * col + amb[ch]);
       g_col[ch] = g_im[ch] * w * alb[ch];
-      g_amb[ch] += (float)(g_im[ch] * alb[ch]);
+      g_amb[ch] += g_im[ch] * alb[ch];
     }
     g_w *= vl;                                                  // d im / d (unshadowed weight)
-    g_cf[0] += (float)(g_w * ndotl);
-    g_cf[1] += (float)(g_w * P);
-    if (rdotc > 0.0) g_cf[2] += (float)(g_w * cf[1] * P) * logf((float)rdotc);
-    const double g_nd = (T.nd > 0.0) ? g_w * cf[0] : 0.0;
-    const double g_rd = (T.rd > 0.0 && cf[2] != 0.0) ? g_w * cf[1] * cf[2] * (double)powf((float)rdotc, (float)(cf[2] - 1.0)) : 0.0;
-    double g_ldn = g_rd * sgn * 2.0 * cdotn + g_nd * sgn * T.afac;
-    g_cdotn += g_rd * sgn * 2.0 * T.ldn;
-    const double g_cl = -g_rd * sgn;
-    const double g_afac = g_nd * sgn * T.ldn;
-    const double g_den = T.den_ok ? -g_afac * T.afac * T.afac : 0.0;
-    const double kl = F.latt ? (double)F.latt[3 * l + 1] : 0.0, kq = F.latt ? (double)F.latt[3 * l + 2] : 0.0;
-    const double d2 = T.dist * T.dist;
-    const double dp = (pw == 4) ? d2 * d2 : d2;
-    const double ddp = (pw == 4) ? 4.0 * d2 * T.dist : 2.0 * T.dist;
-    const double g_dist = g_den * (kl + kq * ddp);
-    double g_lh[3], g_v[3];
+    g_cf[0] += g_w * ndotl;
+    g_cf[1] += g_w * P;
+    if (rdotc > 0.0f) g_cf[2] += (g_w * cf[1] * P) * logf(rdotc);
+    const float g_nd = (T.nd > 0.0f) ? g_w * cf[0] : 0.0f;
+    const float g_rd = (T.rd > 0.0f && cf[2] != 0.0f) ? g_w * cf[1] * cf[2] * powf(rdotc, cf[2] - 1.0f) : 0.0f;
+    const float g_ldn = g_rd * sgnf * 2.0f * cdotnf + g_nd * sgnf * T.afac;
+    g_cdotnf += g_rd * sgnf * 2.0f * T.ldn;
+    const float g_cl = -g_rd * sgnf;
+    const float g_afac = g_nd * sgnf * T.ldn;
+    const float g_den = T.den_ok ? -g_afac * T.afac * T.afac : 0.0f;
+    const float kl = F.latt ? F.latt[3 * l + 1] : 0.0f, kq = F.latt ? F.latt[3 * l + 2] : 0.0f;
+    const float d2 = T.dist * T.dist;
+    const float dp = (pw == 4) ? d2 * d2 : d2;
+    const float ddp = (pw == 4) ? 4.0f * d2 * T.dist : 2.0f * T.dist;
+    const float g_dist = g_den * (kl + kq * ddp);
+    float g_lh[3], g_v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      g_lh[k] = g_ldn * n[k] + g_cl * cdir[k];
-      g_n[k] += g_ldn * T.lh[k];
-      g_cdir[k] += g_cl * T.lh[k];
+      g_lh[k] = g_ldn * nf[k] + g_cl * cdf[k];
+      g_nf[k] += g_ldn * T.lh[k];
+      g_cdf[k] += g_cl * T.lh[k];
     }
-    const double proj = (T.lh[0] * g_lh[0] + T.lh[1] * g_lh[1]) + T.lh[2] * g_lh[2];
+    const float proj = (T.lh[0] * g_lh[0] + T.lh[1] * g_lh[1]) + T.lh[2] * g_lh[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       g_v[k] = T.nz ? (g_lh[k] - T.lh[k] * proj) / T.dist + g_dist * T.lh[k] : g_lh[k];
-      g_p[k] -= g_v[k];
+      g_pf[k] -= g_v[k];
     }
     if (G.lights_pos) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float sum = wave_sum((float)g_v[k]);
+        const float sum = wave_sum(g_v[k]);
         if (lane == 0 && sum != 0.0f) atomicAdd(G.lights_pos + 4 * l + k, sum);
       }
     }
     if (G.colors) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const float sum = wave_sum((float)g_col[ch]);
+        const float sum = wave_sum(g_col[ch]);
         if (lane == 0 && sum != 0.0f) atomicAdd(G.colors + 3 * ci + ch, sum);
       }
     }
     if (G.attenuation) {
-      const double ga[3] = {g_den, g_den * T.dist, g_den * dp};
+      const float ga[3] = {g_den, g_den * T.dist, g_den * dp};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float sum = wave_sum((float)ga[k]);
+        const float sum = wave_sum(ga[k]);
         if (lane == 0 && sum != 0.0f) atomicAdd(G.attenuation + 3 * l + k, sum);
       }
     }
   }
+  // back to fp64 for the geometry chain below
+  double g_n[3] = {(double)g_nf[0], (double)g_nf[1], (double)g_nf[2]}, g_p[3] = {(double)g_pf[0], (double)g_pf[1], (double)g_pf[2]};
+  double g_cdir[3] = {(double)g_cdf[0], (double)g_cdf[1], (double)g_cdf[2]};
+  const double g_cdotn = (double)g_cdotnf;
   if (G.ambient) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {

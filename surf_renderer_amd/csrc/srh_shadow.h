@@ -27,7 +27,19 @@
 
 namespace srh {
 
-constexpr int kShadowRes = 2048;                  // virtual pixels per side of a light view
+// Virtual pixels per side of a light view.  A shadow ray is a POINT query into the view's 16 x 16-pixel tile bins, so
+// the resolution only sets how fine the bins are: finer bins mean shorter lists per query (at 2048 a bin of BASELINE
+// config 5 holds ~90 candidates of which a ray's line meets ~14) but more (primitive, tile) claims in the binning -- and
+// a primitive whose image exceeds 64 tiles goes to the frame-wide list that EVERY query tests.  Measured, shadow pass
+// alone: config 5 (100 k discs of radius 0.02) 3.91 ms at 2048, 2.87 at 4096, 3.90 at 8192; bunny.obj at 512^2
+// 0.60 / 1.31 / 18.9 ms.  So every light picks its own resolution, 2048 or 4096, from the mean size of the scene's
+// primitives (k_scene_bounds): the finer one while a mean primitive stays within ~3 tiles across.
+#ifndef SRH_SHADOW_RES
+#define SRH_SHADOW_RES 4096
+#endif
+constexpr int kShadowRes = SRH_SHADOW_RES;        // the largest view: workspace slices are sized for it
+constexpr int kShadowResCoarse = 2048;
+constexpr double kShadowFineMaxTiles = 3.2;       // mean primitive diameter, in tiles, up to which the fine view is taken
 
 // monotonic int encoding of a float, for atomicMin / atomicMax
 __device__ __forceinline__ int ordered_int(float f) {
@@ -36,11 +48,12 @@ __device__ __forceinline__ int ordered_int(float f) {
 }
 __device__ __forceinline__ float ordered_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-// bounds: [0..2] min xyz, [3..5] max xyz (ordered ints), [6] = 1 if a non-finite extent was seen
+// bounds: [0..2] min xyz, [3..5] max xyz (ordered ints), [6] = 1 if a non-finite extent was seen,
+// [7] sum of the finite primitives' radii (float bits; a triangle counts half its longest edge), [8] their number
 __global__ void k_bounds_init(int* bounds) {
   if (threadIdx.x < 3) bounds[threadIdx.x] = ordered_int(3.0e38f);
   else if (threadIdx.x < 6) bounds[threadIdx.x] = ordered_int(-3.0e38f);
-  else if (threadIdx.x == 6) bounds[6] = 0;
+  else if (threadIdx.x < 9) bounds[threadIdx.x] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_scene_bounds(FrameDev F, int s, int* bounds) {
@@ -48,18 +61,29 @@ __global__ __launch_bounds__(256) void k_scene_bounds(FrameDev F, int s, int* bo
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   bool bad = false;
+  float size = 0.0f, one = 0.0f;
   if (i < S.count && S.type != SRH_PRIM_PLANE) {
     if (S.type == SRH_PRIM_TRIANGLE) {
       const float* f = S.face + 12 * (size_t)i;
       for (int v = 0; v < 3; ++v)
         for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], f[4 * v + k]); hi[k] = fmaxf(hi[k], f[4 * v + k]); bad |= !isfinite(f[4 * v + k]); }
+      size = 0.5f * fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     } else {
       const float* c = S.pos + 4 * (size_t)i;
       const float r = fabsf(S.radius[i]);
       for (int k = 0; k < 3; ++k) { lo[k] = c[k] - r; hi[k] = c[k] + r; bad |= !isfinite(lo[k]) || !isfinite(hi[k]); }
+      size = r;
     }
+    one = 1.0f;
   }
   if (__builtin_amdgcn_ballot_w64(bad)) { if ((threadIdx.x & 63) == 0) bounds[6] = 1; }
+  if (bad) { size = 0.0f; one = 0.0f; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { size += __shfl_xor(size, m); one += __shfl_xor(one, m); }
+  if ((threadIdx.x & 63) == 0 && one > 0.0f && isfinite(size)) {
+    atomicAdd(reinterpret_cast<float*>(bounds + 7), size);
+    atomicAdd(bounds + 8, (int)one);
+  }
   if (bad) return;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -119,6 +143,24 @@ __global__ void k_light_frames(FrameDev T, const float* __restrict__ lpos, int n
   }
   F.focal = 1.0;
   F.half_w = F.half_h = half;
+  // resolution: the template is the fine view; a light whose view would make the mean primitive span more than
+  // kShadowFineMaxTiles tiles takes the coarse one (same workspace slice, fewer and larger bins)
+  if (ok && kShadowRes > kShadowResCoarse) {
+    const double mean = bounds[8] > 0 ? (double)__int_as_float(bounds[7]) / (double)bounds[8] : 0.0;
+    const double tiles_fine = (2.0 * mean) / (2.0 * half * dist) * (double)kShadowRes / (double)kTile;
+    if (!(tiles_fine <= kShadowFineMaxTiles)) {
+      const long long words = (long long)F.bin_cap * (long long)F.nbins;       // this slice's bin-list words
+      F.W = F.H = kShadowResCoarse;
+      F.row0 = 0; F.row1 = kShadowResCoarse;
+      F.step_x = 2.0 / (kShadowResCoarse - 1);
+      F.step_y = -2.0 / (kShadowResCoarse - 1);
+      F.tiles_x = F.tiles_y = kShadowResCoarse / kTile;
+      F.ntiles = F.tiles_x * F.tiles_y;
+      F.ntiles_pad = (F.ntiles + 3) / 4 * 4;
+      F.nbins = F.nseg * F.ntiles_pad;
+      F.bin_cap = (int32_t)min(words / (long long)F.nbins, 1ll << 20);
+    }
+  }
   F.near_clip = 1.0e-300;                                   // "> 0": occluders behind the light camera are not binned
   F.far_clip = 1.0e300;
   F.div_shared = 0;
@@ -128,12 +170,61 @@ __global__ void k_light_frames(FrameDev T, const float* __restrict__ lpos, int n
 }
 
 // Image point (continuous pixel coordinates) of the unit direction w seen from light view LF; false if behind it.
-__device__ __forceinline__ bool light_image_point(const FrameDev& LF, const double w[3], double& c, double& r) {
+// `len` = length of the view's un-normalised ray direction through that point (D = (focal / Zn) w).
+__device__ __forceinline__ bool light_image_point(const FrameDev& LF, const double w[3], double& c, double& r, double& len) {
   const double X = dot3(w, LF.bx), Y = dot3(w, LF.by), Zn = -dot3(w, LF.bz);
   if (!(Zn > 0.0)) return false;
   const double xs = (LF.focal * X / Zn) / LF.half_w, ys = (LF.focal * Y / Zn) / LF.half_h;
   c = (xs + 1.0) / LF.step_x;
   r = (ys - 1.0) / LF.step_y;
+  len = LF.focal / Zn;
+  return true;
+}
+
+// Can the BINNED primitive whose light-view reject record this is block the shadow ray that leaves the light through
+// the image point (c, r)?  Two proofs of "no", the ones the primary pass uses per pixel (srh_reject.h), evaluated here
+// in fp64 on the stored fp32 coefficients at a continuous position (the records' margins cover positions between
+// pixel centres: they are stated in pixels, and a bin's rectangle is already grown by bin_pad for the same reason):
+//   shape   the ray's line misses the inflated ellipse / lies outside an inflated triangle edge;
+//   depth   the record's inverse-depth bound puts every hit on the ray's line farther from the light than
+//           `reach` = |L - fragment| - 0.1, where a blocker cannot be (it must lie between the ray's origin, 0.1 in
+//           front of the fragment, and the light); a plane provably behind the light (den <= hi_u) cannot block
+//           either -- primitives within 0.1 of the light never come here: they are on the frame-wide lists.
+// Candidates that pass go through the exact fp64 test as before, so the result does not change.
+// MEASURED AND NOT ADOPTED (-DSRH_SHADOW_PRETEST): every lane walks its own list, so the reject record is one more
+// scattered 48-byte fetch per entry in front of the 64-byte exact record, and the test itself is no cheaper than the
+// exact one it saves: shadow pass of config 5 3.9 -> 5.4 ms, 20 k discs at 512^2 0.31 -> 0.38 ms.
+__device__ __forceinline__ bool shadow_candidate(int type, const float* __restrict__ rec, double c, double r, double len,
+                                                 double reach) {
+  double den = 0.0, hi = 0.0;
+  bool planar = true;
+  if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) {
+    const double dc = c - (double)rec[0], dr = r - (double)rec[1];
+    const double q = dc * ((double)rec[2] * dc + (double)rec[3] * dr) + (double)rec[4] * dr * dr - 1.0;
+    if (q > 1.0e-6) return false;
+    if (type == SRH_PRIM_SPHERE) {
+      planar = false;
+      const double inv = rec[5];                                       // >= 1 / t for every hit on the sphere; 1e30: none
+      if (inv < 1.0e29 && inv * reach * 1.000001 < 1.0) return false;
+    } else {
+      den = (double)rec[5] + c * (double)rec[6] + r * (double)rec[7];
+      hi = rec[10];
+    }
+  } else if (type == SRH_PRIM_TRIANGLE) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if ((double)rec[4 * i] * c + (double)rec[4 * i + 1] * r + (double)rec[4 * i + 2] < -1.0e-6) return false;
+    den = (double)rec[3] + c * (double)rec[7] + r * (double)rec[11];
+    hi = rec[14];
+  } else {
+    den = (double)rec[0] + c * (double)rec[1] + r * (double)rec[2];
+    hi = rec[5];
+  }
+  if (planar) {
+    if (den <= hi) return false;                                       // behind the light on this ray
+    // den / len >= 1 / t: the hit is at least len / den from the light
+    if (den < 1.0e29 && den * reach * 1.000001 < len) return false;
+  }
   return true;
 }
 
@@ -187,6 +278,8 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
       const double ts = hit_any64_from(B.type, B.rec64 + (size_t)(g - B.first) * kRec64Stride[B.type], F.o, q, dir);
       if (ts > 0.0 && ts < dist && (ts < tmin || (ts == tmin && g < blocker))) { tmin = ts; blocker = g; }
     };
+    const double reach = dist - 0.1;                      // a blocker lies closer to the light than this
+    (void)reach;
     const FrameDev& LF = LFs[l];
     if (!LF.view_valid || !isfinite(dist)) {
       // no usable light view: every primitive, as the all-pairs pass does
@@ -195,8 +288,8 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
     } else {
       // where the ray leaves the light: direction from the light towards the fragment
       const double w[3] = {-dir[0], -dir[1], -dir[2]};
-      double lc = 0.0, lr = 0.0;
-      const bool front = light_image_point(LF, w, lc, lr);
+      double lc = 0.0, lr = 0.0, llen = 1.0;
+      const bool front = light_image_point(LF, w, lc, lr, llen);
       const bool inside = front && lc >= 0.0 && lr >= 0.0 && lc <= (double)(LF.W - 1) && lr <= (double)(LF.H - 1);
       const int tile = inside ? ((int)lr / kTile) * LF.tiles_x + (int)lc / kTile : 0;
       for (int sg = 0; sg < F.nseg; ++sg) {
@@ -207,7 +300,16 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
           const int bin = sg * LF.ntiles_pad + tile;
           const uint32_t* list = bin_list(LF, bin);
           const uint32_t nlist = bin_length(LF, bin);
-          for (uint32_t i = 0; i < nlist; ++i) test(sg, (int)list[i]);
+          const SegDev& LS = LF.seg[sg];
+          const int stride = rec32_stride(LS.type);
+          (void)stride;
+          for (uint32_t i = 0; i < nlist; ++i) {
+            const int g = (int)list[i];
+#ifdef SRH_SHADOW_PRETEST      // measured and dropped: config 5 3.9 -> 5.4 ms (a second scattered record per entry)
+            if (!shadow_candidate(LS.type, LS.rec32 + (size_t)(g - LS.first) * stride, lc, lr, llen, reach)) continue;
+#endif
+            test(sg, g);
+          }
         }
       }
     }

@@ -40,6 +40,35 @@ def all_slabs(height: int, world: int) -> List[Tuple[int, int]]:
     return [row_slab(height, g, world) for g in range(world)]
 
 
+def cost_weighted_slabs(tile_row_cost, height: int, world: int, granule: int = 16,
+                        per_tile_row: float = 0.0) -> List[Tuple[int, int]]:
+    """Contiguous row slabs, in rank order, whose WORK is equal rather than their height.  With tile bins the cost of a
+    row is not uniform (SURVEY 8e's caveat): at BASELINE config 5 the middle slabs of eight see twice the candidates of
+    the outer ones and set the pace.  ``tile_row_cost[i]`` = work of tile row i (``granule`` image rows; e.g.
+    ``renderer.bin_statistics(...)["tile_row_cost"]`` of one probe frame, identical on every rank because the scene
+    replicas are), ``per_tile_row`` = a fixed cost added to every tile row (empty tiles still cost their background
+    stores).  Boundaries are multiples of ``granule``; every rank gets at least one tile row; the prefix sums of the
+    slabs' costs are as close to k / world of the total as whole tile rows allow."""
+    import numpy as np
+    if world < 1:
+        raise ValueError(f"world {world}")
+    cost = np.asarray(tile_row_cost, dtype=np.float64) + float(per_tile_row)
+    nrows = (height + granule - 1) // granule
+    if cost.shape != (nrows,):
+        raise ValueError(f"{cost.shape[0] if cost.ndim == 1 else cost.shape} tile rows of cost for {nrows} tile rows of image")
+    if world > nrows:
+        raise ValueError(f"{world} ranks for {nrows} tile rows")
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for k in range(1, world):
+        want = cum[-1] * k / world
+        at = int(np.argmin(np.abs(cum - want)))
+        at = min(max(at, cuts[-1] + 1), nrows - (world - k))     # at least one tile row for this rank and for those after it
+        cuts.append(at)
+    cuts.append(nrows)
+    return [(cuts[g] * granule, min(cuts[g + 1] * granule, height)) for g in range(world)]
+
+
 def owner_slabs(height: int, world: int, owner_frac: float, granule: int = 16) -> List[List[Tuple[int, int]]]:
     """Owner-weighted row partition for the batched collection: ``rows[k][g]`` = the rows rank g renders of the frame
     that rank k assembles.  The owner takes about ``owner_frac`` of the frame, the others share the rest equally; the
@@ -80,15 +109,21 @@ class GatherHandle:
 
 
 def gather_rows(slab: torch.Tensor, full: Optional[torch.Tensor], height: int, dst: int = 0,
-                group: Optional[dist.ProcessGroup] = None, async_op: bool = False) -> GatherHandle:
+                group: Optional[dist.ProcessGroup] = None, async_op: bool = False,
+                slabs: Optional[List[Tuple[int, int]]] = None) -> GatherHandle:
     """Collect per-rank row slabs ``slab`` ((h_g, W, ...) contiguous) into ``full`` ((H, W, ...), only
     needed on ``dst``).  Equal slabs use one ``gather`` whose receive list are views of ``full`` (no
     staging copy); ragged slabs fall back to one batched send/recv group.  With ``async_op`` the call
     returns at once and the handle's ``wait()`` orders later work on the current stream after the transfer,
-    which lets the next frame's render overlap this frame's gather."""
+    which lets the next frame's render overlap this frame's gather.  ``slabs`` = the ranks' row ranges when they are
+    not ``row_slab``'s (``cost_weighted_slabs``); the same list on every rank."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    slabs = all_slabs(height, world)
+    if slabs is None:
+        slabs = all_slabs(height, world)
+    elif len(slabs) != world or slabs[0][0] != 0 or slabs[-1][1] != height or \
+            any(slabs[g][1] != slabs[g + 1][0] for g in range(world - 1)):
+        raise ValueError(f"slabs {slabs} do not partition {height} rows over {world} ranks")
     if world == 1:
         if full is not None and full.data_ptr() != slab.data_ptr():
             full.copy_(slab)

@@ -439,6 +439,36 @@ def render_buffers(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[
     return image, depth, nearest
 
 
+def bin_statistics(buf: SceneBuffers, cam: _lib.SrhCamera, rows: Optional[Tuple[int, int]] = None) -> Dict[str, Any]:
+    """What one binned frame really tests (measurement; synchronises).  Runs the frame's binning stage alone on a scratch
+    workspace of its own and reads the list lengths back: ``entries`` (batches, tile rows, tile columns) = candidates of
+    every 16 x 16-pixel tile's bins, ``wide`` (batches,) = primitives on the frame-wide lists that every tile tests,
+    ``executed_pair_tests`` = sum over tiles of (bin entries + frame-wide entries) x 256 pixels -- the (pixel, primitive)
+    pairs that go through the fp32 reject test, against ``algorithmic_pair_tests`` = primitives x pixels that the
+    reference evaluates -- and ``tile_row_cost``, the per-tile-row sums ``dist.cost_weighted_slabs`` partitions."""
+    lib = _lib.load()
+    width, height = frame_size(cam)
+    r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
+    ws = buf.new_workspace(width, height)
+    image = torch.empty((r1 - r0, width, 3), dtype=torch.float32, device=buf.device)
+    depth = torch.empty((r1 - r0, width), dtype=torch.float32, device=buf.device)
+    render_buffers(buf, cam, rows=(r0, r1), mode="binned", out=(image, depth, None), workspace=ws, stages=_lib.STAGE_BIN)
+    off, tx, ty, pad, cap = C.c_size_t(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.check(lib.srh_bin_counters(C.byref(buf.objects), width, height, r0, r1, C.byref(off), C.byref(tx), C.byref(ty),
+                                    C.byref(pad), C.byref(cap)))
+    nseg = buf.objects.n_segments
+    words = ws[off.value:off.value + 4 * (64 + nseg * pad.value)].view(torch.int32).cpu().numpy().astype(np.int64)
+    which = int(words[9]) & 1
+    wide = np.minimum(words[4 * which:4 * which + nseg], np.asarray(buf.counts, dtype=np.int64))
+    bins = words[64:64 + nseg * pad.value].reshape(nseg, pad.value)[:, :tx.value * ty.value]
+    entries = np.minimum(bins, cap.value).reshape(nseg, ty.value, tx.value)
+    per_tile = entries.sum(axis=0) + int(wide.sum())
+    return {"entries": entries, "wide": wide, "bin_capacity": cap.value,
+            "executed_pair_tests": int(per_tile.sum()) * 256,
+            "algorithmic_pair_tests": int(buf.total) * (r1 - r0) * width,
+            "tile_row_cost": per_tile.sum(axis=1)}
+
+
 def generate_rays(camera: Dict[str, Any], device="cuda", rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """``ray_dir`` as the reference returns it: (4, N) unit directions, row-major over the image
     (numpy/renderer.py:145-169)."""
@@ -515,58 +545,67 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_image, g_depth, _g_nearest):
-        buf, cam = ctx.buf, ctx.cam
         if ctx.has_vis:
             depth, nearest, vis = ctx.saved_tensors
         else:
             (depth, nearest), vis = ctx.saved_tensors, None
-        lib = _lib.load()
-        width, height = frame_size(cam)
-        r0, r1 = (0, height) if ctx.rows is None else (int(ctx.rows[0]), int(ctx.rows[1]))
-        keys = _float_keys(buf, ctx.shade[0])
-        need = ctx.needs_input_grad[5:]
-        grads: Dict[str, torch.Tensor] = {}
-        sg = _lib.SrhGrads()
-        for key, want in zip(keys, need):
-            if not want:
-                continue
-            g = torch.zeros_like(buf.tensors[key])
-            grads[key] = g
-            if key == "lights.pos":
-                sg.lights_pos = g.data_ptr()
-            elif key == "colors":
-                sg.colors = g.data_ptr()
-            elif key == "materials.albedo":
-                sg.albedo = g.data_ptr()
-            elif key == "materials.coeffs":
-                sg.coeffs = g.data_ptr()
-            elif key == "lights.attenuation":
-                sg.attenuation = g.data_ptr()
-            elif key == "lights.ambient":
-                sg.ambient = g.data_ptr()
-            else:
-                kind, name = key.split(".")
-                s = buf.kinds.index(kind)
-                if name == "radius" and kind == "disk":
-                    continue                      # identically zero (numpy/renderer.py:88: the radius only feeds a mask)
-                getattr(sg, name)[s] = g.data_ptr()
-        g_image = g_image.to(torch.float32).contiguous() if g_image is not None else \
-            torch.zeros((r1 - r0, width, 3), dtype=torch.float32, device=buf.device)
-        g_depth = g_depth.to(torch.float32).contiguous() if g_depth is not None else None
-        params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[ctx.mode],
-                                tonemap_gamma=0 if buf.gamma is None else 1,
-                                gamma=1.0 if buf.gamma is None else buf.gamma,
-                                shading=_lib.SHADING[ctx.shade[0]], double_sided=int(bool(ctx.shade[1])),
-                                use_quartic=int(bool(ctx.shade[2])),
-                                visibility=vis.data_ptr() if vis is not None else None)
-        workspace = buf.ensure_workspace(width, height)
-        with torch.cuda.device(buf.device):
-            rc = lib.srh_render_bwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
-                                    C.byref(params), workspace.data_ptr(), workspace.numel(),
-                                    g_image.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
-                                    nearest.data_ptr(), depth.data_ptr(), C.byref(sg), _stream_ptr(buf.device))
-        _lib.check(rc)
+        keys = _float_keys(ctx.buf, ctx.shade[0])
+        grads = _render_backward(ctx.buf, ctx.cam, ctx.rows, ctx.mode, ctx.shade, depth, nearest, vis, g_image, g_depth,
+                                 ctx.needs_input_grad[5:])
         return (None, None, None, None, None) + tuple(grads.get(k) for k in keys)
+
+
+def _render_backward(buf: SceneBuffers, cam: _lib.SrhCamera, rows, mode: str, shade, depth: torch.Tensor,
+                     nearest: torch.Tensor, vis: Optional[torch.Tensor], g_image: Optional[torch.Tensor],
+                     g_depth: Optional[torch.Tensor], need: Sequence[bool]) -> Dict[str, torch.Tensor]:
+    """srh_render_bwd: gradients of the inputs named by ``_float_keys`` (those with ``need``) for the upstream gradients
+    of image and depth, from the winners the forward pass saved.  Everything is enqueued on the current stream."""
+    lib = _lib.load()
+    width, height = frame_size(cam)
+    r0, r1 = (0, height) if rows is None else (int(rows[0]), int(rows[1]))
+    keys = _float_keys(buf, shade[0])
+    grads: Dict[str, torch.Tensor] = {}
+    sg = _lib.SrhGrads()
+    for key, want in zip(keys, need):
+        if not want:
+            continue
+        g = torch.zeros_like(buf.tensors[key])
+        grads[key] = g
+        if key == "lights.pos":
+            sg.lights_pos = g.data_ptr()
+        elif key == "colors":
+            sg.colors = g.data_ptr()
+        elif key == "materials.albedo":
+            sg.albedo = g.data_ptr()
+        elif key == "materials.coeffs":
+            sg.coeffs = g.data_ptr()
+        elif key == "lights.attenuation":
+            sg.attenuation = g.data_ptr()
+        elif key == "lights.ambient":
+            sg.ambient = g.data_ptr()
+        else:
+            kind, name = key.split(".")
+            s = buf.kinds.index(kind)
+            if name == "radius" and kind == "disk":
+                continue                      # identically zero (numpy/renderer.py:88: the radius only feeds a mask)
+            getattr(sg, name)[s] = g.data_ptr()
+    g_image = g_image.to(torch.float32).contiguous() if g_image is not None else \
+        torch.zeros((r1 - r0, width, 3), dtype=torch.float32, device=buf.device)
+    g_depth = g_depth.to(torch.float32).contiguous() if g_depth is not None else None
+    params = _lib.SrhParams(row0=r0, row1=r1, mode=_lib.MODES[mode],
+                            tonemap_gamma=0 if buf.gamma is None else 1,
+                            gamma=1.0 if buf.gamma is None else buf.gamma,
+                            shading=_lib.SHADING[shade[0]], double_sided=int(bool(shade[1])),
+                            use_quartic=int(bool(shade[2])),
+                            visibility=vis.data_ptr() if vis is not None else None)
+    workspace = buf.ensure_workspace(width, height)
+    with torch.cuda.device(buf.device):
+        rc = lib.srh_render_bwd(C.byref(cam), C.byref(buf.objects), C.byref(buf.lights), C.byref(buf.materials),
+                                C.byref(params), workspace.data_ptr(), workspace.numel(),
+                                g_image.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
+                                nearest.data_ptr(), depth.data_ptr(), C.byref(sg), _stream_ptr(buf.device))
+    _lib.check(rc)
+    return grads
 
 
 _OVERRIDE_FIELDS = {"lights.pos": ("lights", "pos"), "lights.color_idx": ("lights", "color_idx"),
@@ -843,8 +882,10 @@ class ResidentScene:
         # COPIED once by flatten_scene (the copy stays attached to autograd, so its gradients still reach the leaf and
         # the optimiser keeps stepping it) -- and every later render() would draw the first iteration's values.
         stale = []
+        self.leaves: Dict[str, torch.Tensor] = {}           # the caller's own differentiable leaves, by flat key
         for key, leaf in _source_leaves(scene).items():
             if isinstance(leaf, torch.Tensor) and leaf.requires_grad and key in self.buf.tensors:
+                self.leaves[key] = leaf
                 t = self.buf.tensors[key]
                 if t.data_ptr() != leaf.data_ptr() or t.dtype != leaf.dtype or t.device != leaf.device:
                     stale.append(f"{key} ({str(leaf.dtype).replace('torch.', '')} on {leaf.device}"
@@ -865,6 +906,71 @@ class ResidentScene:
             image, depth, nearest = render_buffers(self.buf, self.cam, rows=rows, mode=self.mode, shading=self.shading,
                                                    double_sided=self.shade[1], use_quartic=self.shade[2])
         return RenderResult(self._camera, self.device, image=image, depth=depth, nearest=nearest)
+
+    def capture_step(self, loss_fn, warmup: int = 3) -> "CapturedStep":
+        """One optimisation step's GPU work -- render, ``loss_fn(result)``, backward -- captured as ONE hipGraph and
+        replayed per iteration: the Python side of an iteration (autograd bookkeeping, descriptor structs, ~20 kernel
+        launches) then costs one graph launch.  See ``CapturedStep``."""
+        return CapturedStep(self, loss_fn, warmup)
+
+
+class CapturedStep:
+    """``step = rs.capture_step(loss_fn)``; then per iteration ``loss = step.replay(); optimiser.step()``.
+
+    The whole-step capture recipe of torch.cuda.graphs: a few eager iterations on a side stream, then one iteration
+    recorded into a graph -- the library's forward, ``loss_fn`` on the rendered image and depth, torch's own backward of
+    the loss down to image and depth, and the library's backward from there to the leaves, called directly.  (Letting
+    the autograd engine run the renderer's autograd.Function inside a capture ends in a segmentation fault in
+    hipStreamEndCapture on ROCm 7.2 -- tools/diag_capture.py; each of the pieces used here captures fine.)  The
+    leaves' ``.grad`` tensors are static: every replay overwrites them (they do not accumulate), ``loss`` and
+    ``result`` are static tensors too.
+    What a replay reads is device memory only -- the leaves (an optimiser's in-place step is seen by the next replay)
+    and whatever tensors ``loss_fn`` closes over (update a target with ``copy_``) -- while the camera and everything
+    else on the host was frozen at capture time."""
+
+    def __init__(self, rs: ResidentScene, loss_fn, warmup: int = 3):
+        if not rs.differentiable:
+            raise ValueError("capture_step needs at least one leaf that requires grad")
+        self.rs = rs
+        keys = _float_keys(rs.buf, rs.shading)
+        # the CALLER's leaves (rs.inputs are reshaped views of them: autograd reaches the leaves through the views, a
+        # hand-made .grad has to be put on the leaves themselves)
+        self.keys = [k for k in keys if k in rs.leaves]
+        self.leaves = [rs.leaves[k] for k in self.keys]
+        current = torch.cuda.current_stream(rs.device)
+        side = torch.cuda.Stream(rs.device)
+        side.wait_stream(current)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):        # module load, allocator, the scratch's bin counters
+                for t in self.leaves:
+                    t.grad = None
+                loss_fn(rs.render()).backward()
+        current.wait_stream(side)
+        torch.cuda.synchronize(rs.device)
+        for t in self.leaves:
+            t.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        need = [k in rs.leaves for k in keys]
+        with torch.cuda.graph(self.graph):
+            with torch.no_grad():
+                image, depth, nearest = render_buffers(rs.buf, rs.cam, mode=rs.mode, shading=rs.shading,
+                                                       double_sided=rs.shade[1], use_quartic=rs.shade[2])
+            img, dep = image.requires_grad_(), depth.requires_grad_()
+            self.result = RenderResult(rs._camera, rs.device, image=img, depth=dep, nearest=nearest)
+            self.loss = loss_fn(self.result)
+            g_img, g_dep = torch.autograd.grad(self.loss, [img, dep], allow_unused=True)
+            got = _render_backward(rs.buf, rs.cam, None, rs.mode, rs.shade, depth, nearest, None, g_img, g_dep, need)
+        # the static gradient tensors every replay writes, in the order of self.leaves and in the leaves' own shapes
+        self.grads = [(got[k] if k in got else torch.zeros_like(rs.buf.tensors[k])).view(leaf.shape)
+                      for k, leaf in zip(self.keys, self.leaves)]
+        for t, g in zip(self.leaves, self.grads):
+            t.grad = g
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        for t, g in zip(self.leaves, self.grads):          # whatever happened to .grad in between (zero_grad(set_to_none))
+            t.grad = g
+        return self.loss
 
 
 def _norm_depth_image(depth: torch.Tensor, far: float) -> torch.Tensor:

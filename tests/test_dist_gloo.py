@@ -34,7 +34,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, height, width, q):
+def _worker(rank, world, port, height, width, q, cost=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -42,9 +42,11 @@ def _worker(rank, world, port, height, width, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from oracle import np_oracle
         from surf_renderer_amd import synthetic
+        from surf_renderer_amd.dist import cost_weighted_slabs
         from surf_renderer_amd.scene import scene_to_numpy
         scene = scene_to_numpy(synthetic.demo_scene(width, height, with_planes=True), round_fp32=True)
-        r0, r1 = row_slab(height, rank, world)
+        slabs = cost_weighted_slabs(cost, height, world) if cost is not None else None
+        r0, r1 = slabs[rank] if slabs else row_slab(height, rank, world)
         part = np_oracle.render(scene, rows=(r0, r1))
         # the bench's framebuffer layout: one (rows, 4W) slab, [W x rgb | W x depth] per row
         if rank == 0:
@@ -57,7 +59,7 @@ def _worker(rank, world, port, height, width, q):
         depth = slab.as_strided((r1 - r0, width), (4 * width, 1), slab.storage_offset() + 3 * width)
         image.copy_(torch.from_numpy(part["image"].astype(np.float32)))
         depth.copy_(torch.from_numpy(part["depth"].astype(np.float32)))
-        gather_rows(slab, frame, height, dst=0, async_op=(height % 2 == 0)).wait()
+        gather_rows(slab, frame, height, dst=0, async_op=(height % 2 == 0), slabs=slabs).wait()
         if rank == 0:
             full = np_oracle.render(scene)
             fb = frame.numpy()
@@ -82,6 +84,47 @@ def test_two_rank_row_slab_gather(height):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cost_weighted_slabs_assemble_the_whole_frame(world):
+    """Ranks render slabs of equal WORK (here: a made-up cost per tile row, heavy in the middle) and rank 0 still
+    receives every row exactly once."""
+    height = 80
+    cost = [1, 1, 9, 30, 2]                              # five tile rows of 16 image rows
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, height, 40, q, cost)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_cost_weighted_slabs_balance_the_work():
+    from surf_renderer_amd.dist import cost_weighted_slabs
+    rng = np.random.RandomState(0)
+    for height, world in ((2048, 8), (2048, 4), (2048, 2), (1000, 3), (16, 1)):
+        nrows = (height + 15) // 16
+        x = np.linspace(-1, 1, nrows)
+        cost = 100.0 * np.exp(-4 * x * x) + rng.uniform(0, 5, nrows)       # busiest in the middle, like BASELINE config 5
+        slabs = cost_weighted_slabs(cost, height, world)
+        assert slabs[0][0] == 0 and slabs[-1][1] == height
+        assert all(slabs[g][1] == slabs[g + 1][0] for g in range(world - 1))
+        assert all(a % 16 == 0 and b > a for a, b in slabs)
+        work = [cost[a // 16:(b + 15) // 16].sum() for a, b in slabs]
+        equal = [cost[a // 16:(b + 15) // 16].sum() for a, b in
+                 [(g * (height // world) // 16 * 16, (g + 1) * (height // world) // 16 * 16) for g in range(world)]]
+        if world > 1 and nrows >= 8 * world:
+            assert max(work) <= 1.15 * sum(work) / world          # within a tile row's worth of the mean
+            assert max(work) < max(equal) or world == 2
+    with pytest.raises(ValueError):
+        cost_weighted_slabs([1.0] * 3, 64, 2)                     # 4 tile rows, 3 costs
+    with pytest.raises(ValueError):
+        cost_weighted_slabs([1.0] * 2, 32, 3)                     # more ranks than tile rows
 
 
 def _exchange_worker(rank, world, port, q):

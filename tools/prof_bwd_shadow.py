@@ -95,6 +95,14 @@ def main():
             dt = timed(it, args.steps * 5, 5)
             out = {"case": case, "what": "bunny.obj 1024x1024 forward + backward, ResidentScene (scene flattened once)",
                    "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt}
+        elif case in ("bwd_mesh_captured", "bwd_mesh_captured_tch"):
+            sc = synthetic.bunny_mesh_scene(1024, 1024)
+            ps = leaves(sc, "triangle", ("face", "normal"))
+            rs = renderer.ResidentScene(sc, device=DEV, shading="torch" if case.endswith("tch") else "numpy", validate=False)
+            step = rs.capture_step(lambda res: res["image"].sum() + res["depth"].clamp(max=100.0).sum())
+            dt = timed(step.replay, args.steps * 5, 5)
+            out = {"case": case, "what": "bunny.obj 1024x1024 forward + backward, ResidentScene.capture_step (one hipGraph "
+                                         "per iteration)", "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt}
         elif case == "bwd_plane":
             sc = plane_scene(2048, 2048)
             ps = leaves(sc, "plane", ("pos", "normal"))
