@@ -37,7 +37,9 @@ VALU_F32_PEAK_TFLOPS = 157.3
 # profiles/r02_ubench_issue.txt) gives the cycles per wave-instruction per SIMD for every instruction class the kernel
 # uses; the peak below is the rate of its dominant class.
 VALU_PEAK_GINSTR_S = 614.4
-PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")
+# newest committed counter file first (tools/collect_pmc.py; one per round)
+PMC_FILES = [os.path.join(REPO, "profiles", name) for name in ("r03_pmc.json", "r02_pmc.json")]
+MIX_FILE = os.path.join(REPO, "profiles", "r03_valu_mix.json")      # tools/valu_mix.py: the kernel's instruction mix, priced
 
 
 # --schedule auto = whole frames per stream, always.  The stage schedule (binning of every frame on one stream, render
@@ -53,10 +55,11 @@ def load_pmc():
     """Per-launch PMC counters of the render kernel on the default workload, as collected by tools/collect_pmc.py and
     committed under profiles/ together with the commit and the library hash they were taken at.  None when absent."""
     try:
-        with open(PMC_FILE) as fh:
+        path = next(p for p in PMC_FILES if os.path.exists(p))
+        with open(path) as fh:
             d = json.load(fh)
         k = d["kernels"]["k_render_binned"]
-        return {"commit": d.get("commit"), "lib_sha256": d.get("lib_sha256"),
+        return {"commit": d.get("commit"), "lib_sha256": d.get("lib_sha256"), "file": os.path.relpath(path, REPO),
                 # HBM bytes: WRITE_SIZE + 2 x FETCH_SIZE (KiB units; the guide's gfx950 correction for the read side)
                 "traffic_bytes": (k["WRITE_SIZE"] + 2.0 * k["FETCH_SIZE"]) * 1024.0,
                 "valu_wave_instr": float(k["SQ_INSTS_VALU"])}
@@ -928,7 +931,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": pmc["traffic_bytes"] if pmc else None,
-                         "traffic_source": (f"profiles/r02_pmc.json: rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (separate "
+                         "traffic_source": (f"{pmc['file']}: rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (separate "
                                             f"passes, per launch), taken at commit {pmc['commit']}, libsrh.so sha256 "
                                             f"{str(pmc['lib_sha256'])[:12]} ({lib_match}); not re-measured by this run")
                          if pmc else None,
@@ -950,10 +953,36 @@ def main():
                             "frac": ginstr_s / VALU_PEAK_GINSTR_S,
                             "frac_per_job_time": valu_n / (elapsed / args.steps) / 1e9 / VALU_PEAK_GINSTR_S,
                             "wave_instr_per_launch": valu_n,
-                            "source": f"SQ_INSTS_VALU from profiles/r02_pmc.json (commit {pmc['commit']}) over the live "
-                                      "kernel time; peak = one wave-instruction per SIMD per 4 cycles, the measured issue "
-                                      "cost of the kernel's instruction mix (profiles/r02_ubench_issue.txt)"} if pmc else None),
+                            "source": f"SQ_INSTS_VALU from {pmc['file']} (commit {pmc['commit']}) over the live "
+                                      "kernel time; peak = one wave-instruction per SIMD per 4 cycles "
+                                      "(profiles/r02_ubench_issue.txt); peak_mix_weighted prices the kernel's own mix"}
+                           if pmc else None),
         }
+        if out["valu_issue"] is not None:
+            # the same achieved rate against a ceiling weighted by the kernel's instruction mix: the 2.5-cycle classes
+            # (add / sub / mul_f32, logic, shifts, integer add, mov) are a third of the sweep (tools/valu_mix.py)
+            try:
+                with open(MIX_FILE) as fh:
+                    peak_mix = float(json.load(fh)["launch"]["peak_ginstr_s_mix_weighted"])
+                out["valu_issue"].update(peak_mix_weighted=peak_mix, frac_mix_weighted=ginstr_s / peak_mix,
+                                         frac_per_job_time_mix_weighted=valu_n / (elapsed / args.steps) / 1e9 / peak_mix,
+                                         mix_source=os.path.relpath(MIX_FILE, REPO))
+            except Exception:                                   # noqa: BLE001 -- no file, no figure
+                pass
+        # the pairs the kernel really tests (bin lengths of one frame, read back outside the timed region) beside the
+        # algorithmic primitives x pixels of `gtests_per_s` -- SURVEY 8 f2
+        if args.mode in ("auto", "binned") and not args.as_rank and world == 1:
+            try:
+                st = renderer.bin_statistics(buf, cam)
+                out["executed_pair_tests"] = {"per_frame": st["executed_pair_tests"],
+                                              "algorithmic_per_frame": st["algorithmic_pair_tests"],
+                                              "fraction": st["executed_pair_tests"] / st["algorithmic_pair_tests"],
+                                              "gtests_per_s_executed": fps * st["executed_pair_tests"] / 1e9,
+                                              "tile_list_entries": st["executed_pair_tests"] // 256,
+                                              "what": "(tile, primitive) list entries x 256 pixels: the pairs that go through "
+                                                      "the fp32 reject test; every other pair was ruled out by the binning"}
+            except Exception as exc:                            # noqa: BLE001
+                print(f"[bench] executed_pair_tests not available ({exc!r})", file=sys.stderr)
         if literal is not None:
             out["literal_root0"] = literal
         if literal is not None and not literal.get("failed") and (collection_failed or literal["value"] > out["value"]):

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-launch PMC counters of every kernel of one frame of the default bench workload -> JSON.
 
-    python3 tools/collect_pmc.py --commit <hash> --out gpurun_out/r02_pmc.json        (on the GPU box)
+    python3 tools/collect_pmc.py --commit <hash> --out gpurun_out/r03_pmc.json        (on the GPU box)
 
 One rocprofv3 pass per counter group (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950), each over
 `bench.py --steps 3 --warmup 1 --graph off --inflight 1` (eager launches, one frame in flight: the counters of a launch
 are then that launch's alone).  This script never touches the GPU itself; rocprofv3 starts bench.py directly.
 FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them; bench.py applies the guide's x2 on the read side.
-The file is copied to profiles/r02_pmc.json and committed; bench.py quotes it with the commit and library hash."""
+The file is copied to profiles/rNN_pmc.json and committed; bench.py quotes it with the commit and library hash."""
 import argparse
 import collections
 import csv
