@@ -249,9 +249,17 @@ __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
 }
 
 // (bits(inv) & ~kOrdMask) | field in one v_bfi_b32 (field <= kOrdMask, in a vector register)
+#ifndef SRH_FIELD_SGPR
+#define SRH_FIELD_SGPR 0
+#endif
 __device__ __forceinline__ int32_t pack_key(float inv, uint32_t field) {
   int32_t r;
+#if SRH_FIELD_SGPR   // measurement build: the (wave-uniform) field as the instruction's scalar operand, the mask in a register
+  const uint32_t maskv = 0xFFFFF000u;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(maskv), "v"(inv), "s"(field));
+#else
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFF000u), "v"(inv), "v"(field));
+#endif
   return r;
 }
 
@@ -417,7 +425,9 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
 #pragma unroll
     for (int j = 0; j < 4; ++j) sel[j] = __float_as_int(q[j >> 1][j & 1]) >> 31;
     if (TYPE == SRH_PRIM_DISK) {
-      const float rowden = __builtin_fmaf(R[7], rf, R[5]);
+      // a multiply and an add (2.5 cycles each, one scalar operand each) instead of one fma, which would need a v_mov
+      // for its second scalar operand (one constant-bus read per instruction) and costs 4.7 cycles itself
+      const float rowden = R[7] * rf + R[5];
 #pragma unroll
       for (int p = 0; p < 2; ++p) den[p] = fma2(splat2(R[6]), cf[p], splat2(rowden));
     }
@@ -427,7 +437,7 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
     const float r0 = __builtin_fmaf(R[1], rf, R[2]);
     const float r1 = __builtin_fmaf(R[5], rf, R[6]);
     const float r2 = __builtin_fmaf(R[9], rf, R[10]);
-    const float rowden = __builtin_fmaf(R[11], rf, R[3]);
+    const float rowden = R[11] * rf + R[3];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const f32x2 e0 = fma2(splat2(-R[0]), cf[p], splat2(-r0));
@@ -438,7 +448,7 @@ __device__ __forceinline__ void pair_bounds(const RejectRecord<TYPE>& R, const f
       den[p] = fma2(splat2(R[7]), cf[p], splat2(rowden));
     }
   } else {
-    const float rowden = __builtin_fmaf(R[2], rf, R[0]);
+    const float rowden = R[2] * rf + R[0];
 #pragma unroll
     for (int p = 0; p < 2; ++p) den[p] = fma2(splat2(R[1]), cf[p], splat2(rowden));
 #pragma unroll

@@ -50,7 +50,14 @@
   X(32, "v_min_u32 %0, %0, %1", "v_min_u32 (VOP2)", u, v1)                         \
   X(33, "v_lshl_or_b32 %0, %0, 1, %1", "v_lshl_or_b32 (VOP3)", u, v1)              \
   X(34, "v_sub_f32 %0, %0, %1", "v_sub_f32 (VOP2)", x, fa)                         \
-  X(35, "v_xor_b32 %0, %0, %1", "v_xor_b32 (VOP2)", u, v1)
+  X(35, "v_xor_b32 %0, %0, %1", "v_xor_b32 (VOP2)", u, v1)                         \
+  X(36, "v_cndmask_b32_e64 %0, %0, %1, s[22:23]", "v_cndmask_b32 (SGPR-pair mask)", u, v1) \
+  X(37, "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc", "v_cmp + v_cndmask (PAIR)", u, v1) \
+  X(38, "v_cmp_lt_u32_e64 s[22:23], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[22:23]", "v_cmp_e64 + v_cndmask_e64 (PAIR)", u, v1) \
+  X(39, "v_min_f32 %0, %0, %1", "v_min_f32 (VOP2)", x, fa)                          \
+  X(40, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0xe0", "v_bitop3_b32", u, v1)          \
+  X(41, "v_writelane_b32 %0, s20, 3", "v_writelane_b32", u, v1)                    \
+  X(42, "v_mov_b64 %0, %1", "v_mov_b64", d, da)
 
 constexpr int kIters = 1500;
 constexpr int kPerIter = 32;
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, uint32_
   const double da = fa;
   for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 0.001f + i + 1.0f; u[i] = threadIdx.x * 7 + i; d[i] = x[i]; }
   if (iters < 0) pad[threadIdx.x] = fa;                     // keeps the LDS allocation alive
-  asm volatile("s_mov_b32 s20, 0x3f800100\n s_mov_b32 s21, 0x3f800100" ::: "s20", "s21");
+  asm volatile("s_mov_b32 s20, 0x3f800100\n s_mov_b32 s21, 0x3f800100\n s_mov_b32 s22, 0x55555555\n s_mov_b32 s23, 0x33333333" ::: "s20", "s21", "s22", "s23");
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, uint32_
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-#define X(N, S, LABEL, VAR, OPD) if (KIND == N) asm volatile(S : "+v"(VAR[i]) : "v"(OPD) : "vcc", "s20", "s21");
+#define X(N, S, LABEL, VAR, OPD) if (KIND == N) asm volatile(S : "+v"(VAR[i]) : "v"(OPD) : "vcc", "s20", "s21", "s22", "s23");
         OPS(X)
 #undef X
       }
