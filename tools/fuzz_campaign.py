@@ -32,7 +32,29 @@ def main():
     ap.add_argument("--views", action="store_true",
                     help="instead: render_views (one batch of 2-5 random cameras, perspective or orthographic under torch "
                          "shading) against per-view render(), bit for bit")
+    ap.add_argument("--adversarial", action="store_true",
+                    help="instead: the directed scenes of tests/adversarial_scenes.py (primitives with coordinates of "
+                         "2^30..2^66 that cross the view), all four kinds in turn, with the checks of "
+                         "tests/test_hip_adversarial.py")
     args = ap.parse_args()
+    if args.adversarial:
+        from adversarial_scenes import KINDS, huge_scene
+        import test_hip_adversarial as A
+        rng = np.random.RandomState(args.seed)
+        t0 = time.time()
+        it = off = total = 0
+        while time.time() - t0 < args.seconds:
+            kind = KINDS[it % 4]
+            ref, bad = A.check_scene(huge_scene(rng, kind), f"{kind} seed {args.seed} scene {it}")
+            off += bad
+            total += ref["depth"].size
+            it += 1
+            if it % 200 == 0:
+                print(f"[adversarial seed {args.seed}] {it} scenes, {off} of {total} pixels off the oracle (all won by huge "
+                      f"primitives), modes bit-identical", flush=True)
+        print(f"[adversarial seed {args.seed}] DONE: {it} scenes, modes bit-identical; {off} of {total} pixels "
+              f"({off / max(total, 1):.2e}) differ from the oracle, every one of them won by a huge primitive", flush=True)
+        return
     import test_hip_parity as T
     from surf_renderer_amd import render
     from surf_renderer_amd.scene import scene_to_numpy
