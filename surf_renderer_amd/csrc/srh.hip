@@ -182,6 +182,12 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
 #define SRH_PREP_ATTR __attribute__((amdgpu_waves_per_eu(SRH_PREP_WAVES)))
 template <int TYPE>
 __global__ __launch_bounds__(kBinBlock) SRH_PREP_ATTR void k_prep(FrameDev F, int s, double* rec64, float* rec32) {
+  // the frame's constants into the workspace, where the render kernel reads them (FrameDev::self; srh_binned.h)
+  if (F.self && s == 0 && blockIdx.x == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&F);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(F.self);
+    for (unsigned i = threadIdx.x; i < sizeof(FrameDev) / 4; i += kBinBlock) dst[i] = src[i];
+  }
   prep_body<TYPE>(F, s, rec64, rec32);
 }
 
@@ -535,7 +541,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t lights64, tilerange, counters, large, entries, entries_words;
+  size_t lights64, frame, tilerange, counters, large, entries, entries_words;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -572,6 +578,8 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   size_t off = 0, total = 0;
   L.lights64 = off;
   off = align_up(off + (size_t)SRH_MAX_LIGHTS * 6 * sizeof(double));
+  L.frame = off;                                  // the frame's own constants, for the render kernel (FrameDev::self)
+  off = align_up(off + sizeof(FrameDev));
   for (int s = 0; s < ob->n_segments; ++s) {
     const SrhSegment& g = ob->seg[s];
     L.off64[s] = off;
@@ -816,6 +824,9 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
   const bool abl_skip_binning = !(stages & SRH_STAGE_BIN), abl_skip_render = !(stages & SRH_STAGE_RENDER);
   if (mode == SRH_MODE_BINNED) setup_binning(F, L, workspace);
   F.keep_bins = (stages & SRH_STAGE_KEEP_BINS) ? 1 : 0;
+#if SRH_FRAME_MEM
+  if (mode == SRH_MODE_BINNED) F.self = (FrameDev*)((char*)workspace + L.frame);
+#endif
 #ifdef SRH_ALWAYS_ZERO      // measurement build: the clearing launch of every frame, as before ABI 10
   const bool counters_clean = false;
 #else
@@ -848,13 +859,24 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
     const dim3 g4(groups * 4), b4(256), g1(groups * (4 / kWavesPerGroup1)), b1(64 * kWavesPerGroup1);
     // one object batch of a known type: the instantiation without per-batch generality and without the other types' code
     const int batch = F.nseg == 1 ? F.seg[0].type : -1;
+#if SRH_FRAME_MEM
+    // the render kernel reads the frame's constants from the workspace: k_prep of batch 0 put them there, unless this
+    // call renders from bins an earlier call made
+    if (abl_skip_binning) hipLaunchKernelGGL(k_put_frame, dim3(1), dim3(64), 0, st, F);
+    const FrameConstPtr Fc = (FrameConstPtr)F.self;
+#define SRH_RENDER_KERNEL k_render_binned_mem
+#define SRH_RENDER_FRAME Fc
+#else
+#define SRH_RENDER_KERNEL k_render_binned
+#define SRH_RENDER_FRAME F
+#endif
 #define SRH_LAUNCH_BINNED(TCH_, WPT_, G_, B_)                                                                          \
     switch (batch) {                                                                                                   \
-      case SRH_PRIM_DISK: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_DISK>), G_, B_, 0, st, F, image, depth, nearest); break;       \
-      case SRH_PRIM_PLANE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_PLANE>), G_, B_, 0, st, F, image, depth, nearest); break;     \
-      case SRH_PRIM_SPHERE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_SPHERE>), G_, B_, 0, st, F, image, depth, nearest); break;   \
-      case SRH_PRIM_TRIANGLE: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, SRH_PRIM_TRIANGLE>), G_, B_, 0, st, F, image, depth, nearest); break; \
-      default: hipLaunchKernelGGL((k_render_binned<TCH_, WPT_, -1>), G_, B_, 0, st, F, image, depth, nearest); break;  \
+      case SRH_PRIM_DISK: hipLaunchKernelGGL((SRH_RENDER_KERNEL<TCH_, WPT_, SRH_PRIM_DISK>), G_, B_, 0, st, SRH_RENDER_FRAME, image, depth, nearest); break;       \
+      case SRH_PRIM_PLANE: hipLaunchKernelGGL((SRH_RENDER_KERNEL<TCH_, WPT_, SRH_PRIM_PLANE>), G_, B_, 0, st, SRH_RENDER_FRAME, image, depth, nearest); break;     \
+      case SRH_PRIM_SPHERE: hipLaunchKernelGGL((SRH_RENDER_KERNEL<TCH_, WPT_, SRH_PRIM_SPHERE>), G_, B_, 0, st, SRH_RENDER_FRAME, image, depth, nearest); break;   \
+      case SRH_PRIM_TRIANGLE: hipLaunchKernelGGL((SRH_RENDER_KERNEL<TCH_, WPT_, SRH_PRIM_TRIANGLE>), G_, B_, 0, st, SRH_RENDER_FRAME, image, depth, nearest); break; \
+      default: hipLaunchKernelGGL((SRH_RENDER_KERNEL<TCH_, WPT_, -1>), G_, B_, 0, st, SRH_RENDER_FRAME, image, depth, nearest); break;  \
     }
     if (F.shading) {
       if (split) { SRH_LAUNCH_BINNED(true, 4, g4, b4) } else { SRH_LAUNCH_BINNED(true, 1, g1, b1) }
@@ -862,6 +884,8 @@ int srh_render_fwd(const SrhCamera* camera, const SrhObjects* objects, const Srh
       if (split) { SRH_LAUNCH_BINNED(false, 4, g4, b4) } else { SRH_LAUNCH_BINNED(false, 1, g1, b1) }
     }
 #undef SRH_LAUNCH_BINNED
+#undef SRH_RENDER_KERNEL
+#undef SRH_RENDER_FRAME
   } else if (mode == SRH_MODE_EXACT) {
     const dim3 block(64, 4), grid((F.W + 63) / 64, (F.row1 - F.row0 + 3) / 4);
     if (F.ortho) hipLaunchKernelGGL(k_render_ortho, grid, block, 0, st, F, image, depth, nearest);

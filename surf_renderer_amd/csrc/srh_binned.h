@@ -841,16 +841,6 @@ static_assert(kWavesPerGroup1 == 1 || kWavesPerGroup1 == 4, "SRH_GROUP_WAVES");
 // waves per tile of the render kernel (see k_render_binned): 4 below SRH_SPLIT_TILES tiles, else 1
 __host__ inline int binned_waves_per_tile(const FrameDev& F) { return F.ntiles < SRH_SPLIT_TILES ? 4 : 1; }
 
-// inclusive prefix sum of one int per lane across the wave
-__device__ __forceinline__ int wave_prefix_incl(int v, int lane) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const int o = __shfl_up(v, m);
-    if (lane >= m) v += o;
-  }
-  return v;
-}
-
 // lanes below this one in a ballot mask
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -1076,12 +1066,18 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   }
 
   // queue of the pixels with a candidate, row-major over the tile
+  // (slot of a pixel = pixels with a candidate in the lanes below + those of this lane's quad before it: four ballots
+  // and their v_mbcnt chains -- 16 vector instructions where a shuffle prefix sum took ~35 and six LDS round trips)
   int n1;
   {
-    const int cnt = __popc(has);
-    const int incl = wave_prefix_incl(cnt, lane);
-    int pos = incl - cnt;
-    n1 = __builtin_amdgcn_readlane(incl, 63);
+    int pos = 0;
+    n1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long bj = __builtin_amdgcn_ballot_w64(((has >> j) & 1u) != 0u);
+      pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bj, (uint32_t)pos));
+      n1 += __popcll(bj);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if ((has >> j) & 1u) queue[wave][pos++] = (uint8_t)(j * 64 + lane);
@@ -1090,7 +1086,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   // background: what the fragment stage gives an all-miss pixel (tonemap(0), +inf or far + 1, index 0)
   if (row_live && has != mine) {
     const size_t row = (size_t)(r_raw - F.row0);
-    const float bg = tonemap_f32(F, 0.0);
+    const float bg = tonemap_zero(F);
     const float bgz = background_depth(F, __builtin_inf());
     float* px = image + row * F.img_stride + 3 * (size_t)c0;
     float* dz = depth + row * F.depth_stride + c0;
@@ -1254,6 +1250,31 @@ __global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256)
 __attribute__((amdgpu_waves_per_eu(typed_waves(TCH, BATCH)))) void k_render_binned(
     FrameDev F, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
   render_binned_body<TCH, WPT, BATCH>(F, image, depth, nearest);
+}
+
+// The product form of the same kernel reads its frame constants from MEMORY in the constant address space -- the copy
+// k_prep (or k_put_frame) left in the workspace, FrameDev::self -- instead of from by-value kernel arguments: the loads
+// are invariant scalar loads that hipcc re-materialises where the values are used, where the by-value form keeps ~150
+// scalars alive across the sweep and spills them into vector-register lanes, and every v_writelane / v_readlane of
+// those is a VECTOR instruction (disc kernel: 219 of them in the by-value form, 56 here; 52 -> 22 spilled scalars,
+// 96 -> 93 vector registers).  -DSRH_FRAME_MEM=0 builds the by-value launch for comparison.
+#ifndef SRH_FRAME_MEM
+#define SRH_FRAME_MEM 1
+#endif
+typedef const __attribute__((address_space(4))) FrameDev* FrameConstPtr;
+template <bool TCH, int WPT, int BATCH = -1>
+__global__ __launch_bounds__(WPT == 1 ? 64 * kWavesPerGroup1 : 256)
+__attribute__((amdgpu_waves_per_eu(typed_waves(TCH, BATCH)))) void k_render_binned_mem(
+    FrameConstPtr Fp, float* __restrict__ image, float* __restrict__ depth, int32_t* __restrict__ nearest) {
+  render_binned_body<TCH, WPT, BATCH>(*(const FrameDev*)Fp, image, depth, nearest);
+}
+
+// A frame's constants into its workspace slot: one wave; used when the call that renders did not run k_prep itself
+// (SRH_STAGE_RENDER alone)
+__global__ __launch_bounds__(64) void k_put_frame(FrameDev F) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&F);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(F.self);
+  for (unsigned i = threadIdx.x; i < sizeof(FrameDev) / 4; i += 64) dst[i] = src[i];
 }
 
 // ---- many views per launch (srh_render_views): blockIdx.y selects the view, whose FrameDev lives in device memory;

@@ -79,6 +79,8 @@ struct FrameDev {
   int32_t keep_bins;                 // the render kernel leaves the bin counters alone (SRH_STAGE_KEEP_BINS, light views)
   SegDev seg[SRH_MAX_SEGMENTS];
   const double* lights64;            // (nlights,6) per-frame fp64 copy written by k_prep: position xyz, colour rgb
+  FrameDev* self;                    // binned frames: where in the workspace k_prep leaves a copy of this struct for the
+                                     // render kernel (k_render_binned reads its constants from there, see srh_binned.h)
   const float* lpos;
   const int32_t* lcidx;
   const float* colors;
@@ -322,6 +324,17 @@ __device__ __forceinline__ float tonemap_f32(const FrameDev& F, double v) {
   return powf(x, g);
 }
 
+// tonemap_f32(F, 0.0) in closed form: what every all-miss or depth-masked pixel stores.  0 ** gamma is 0 for gamma > 0
+// (the direct path: exp2(gamma * -inf)), 1 for gamma == 0, +inf for gamma < 0 and NaN for a NaN gamma (powf's special
+// values, the same ones numpy's ** gives).  Spelled out because hipcc hoists the inlined powf(0, gamma) -- ~190 vector
+// instructions on wave-uniform values -- out of the finish loop and runs it once per TILE whether or not any pixel is
+// masked: 3.3 M of the render kernel's 40 M vector instructions per launch at BASELINE config 5.
+__device__ __forceinline__ float tonemap_zero(const FrameDev& F) {
+  if (!F.tonemap) return 0.0f;
+  const float g = (float)F.gamma;
+  return g > 0.0f ? 0.0f : (g == 0.0f ? 1.0f : (g < 0.0f ? __builtin_inff() : g));
+}
+
 // Fragment stage for one pixel (numpy/renderer.py:228-263): gathers the winner's normal / position /
 // albedo, Lambert over all lights with no per-light clamp (Q4, Q5), depth mask, clip, tonemap.
 // `z` is +inf and `win` 0 for an all-miss pixel, exactly what np.argmin hands the reference; whatever
@@ -346,7 +359,7 @@ __device__ __forceinline__ void shade_pixel_t(const FrameDev& F, const double d[
     for (int i = 0; i < 6; ++i) aux[i] = 0.0f;
   }
   if (masked) {
-    rgb[0] = rgb[1] = rgb[2] = tonemap_f32(F, 0.0);
+    rgb[0] = rgb[1] = rgb[2] = tonemap_zero(F);
     return;
   }
   // the winner's batch: with one batch in the scene (wave-uniform test) nothing has to be selected per lane
