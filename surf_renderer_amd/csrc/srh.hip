@@ -162,6 +162,10 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
         dmin = sqrt(near2) - sqrt(far2);                        // every point is within one edge length of a vertex
       }
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
+      // what the shadow pass skips candidates by: no point of the primitive is closer to the light than this (rounded
+      // DOWN to fp32; 0 = unknown: planes, non-finite geometry)
+      const float nd = (TYPE != SRH_PRIM_PLANE && dmin > 0.0 && dmin < 1.0e30) ? (float)dmin * 0.999999f : 0.0f;
+      F.neardist[S.first + i] = nd;
     }
     const TileBox box = bin_primitive(F, s, TYPE, Q, S.first + i, set, near_eye);
 #if SRH_FUSE_BIN
@@ -541,7 +545,7 @@ void launch_fast(const FrameDev& F, hipStream_t st, float* image, float* depth, 
 struct WsLayout {
   size_t off64[SRH_MAX_SEGMENTS];
   size_t off32[SRH_MAX_SEGMENTS];
-  size_t lights64, frame, tilerange, counters, large, entries, entries_words;
+  size_t lights64, frame, tilerange, neardist, counters, large, entries, entries_words;
   size_t counters_bytes;
   int tiles_x, tiles_y_max;
   size_t total;
@@ -593,6 +597,8 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   const size_t ntiles = ((size_t)L.tiles_x * L.tiles_y_max + 3) / 4 * 4;
   L.tilerange = off;
   off = align_up(off + total * 4 * sizeof(uint16_t));
+  L.neardist = off;                                // light views only (FrameDev::neardist)
+  off = align_up(off + total * sizeof(float));
   L.counters = off;
   L.counters_bytes = (kCounterPad + SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
   off = align_up(off + L.counters_bytes);
@@ -781,6 +787,7 @@ static void setup_binning(FrameDev& F, const WsLayout& L, void* workspace) {
   F.bin_cap = (int32_t)std::min<size_t>(L.entries_words / (size_t)F.nbins, 1u << 20);
   char* ws = (char*)workspace;
   F.tilerange = (uint16_t*)(ws + L.tilerange);
+  F.neardist = (float*)(ws + L.neardist);
   F.counters = (uint32_t*)(ws + L.counters);
   F.large = (uint32_t*)(ws + L.large);
   F.entries = (uint32_t*)(ws + L.entries);
@@ -1182,7 +1189,7 @@ int srh_shadow_shade(const SrhCamera* camera, const SrhObjects* objects, const S
   const unsigned V = (unsigned)F.nlights;
   hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, st, bounds);
   for (int s = 0; s < F.nseg; ++s)
-    hipLaunchKernelGGL(k_scene_bounds, dim3((F.seg[s].count + 255) / 256), dim3(256), 0, st, F, s, bounds);
+    hipLaunchKernelGGL(k_scene_bounds, dim3((unsigned)std::min(kBoundsBlocks, (F.seg[s].count + 255) / 256)), dim3(256), 0, st, F, s, bounds);
   hipLaunchKernelGGL(k_light_frames, dim3((V + 63) / 64), dim3(64), 0, st, T, F.lpos, F.nlights, bounds, frames, SL.slice.total);
   const size_t ncount = (size_t)kCounterPad + (size_t)T.nbins;
   hipLaunchKernelGGL(k_views_zero, dim3((unsigned)((ncount + 255) / 256), V), dim3(256), 0, st, frames);

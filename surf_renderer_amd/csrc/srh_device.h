@@ -75,6 +75,9 @@ struct FrameDev {
   // by bin_pad pixels on every side (0 for pixel-centre rendering), and primitives within near_ball of the eye go to
   // the `large` lists (every query tests them).  view_valid = 0: this light has no usable view (all-pairs fallback).
   double bin_pad, near_ball;
+  float* neardist;                   // light views: (total) lower bound of the distance from the eye (= the light) to any
+                                     // point of the primitive, 0 where none is known (srh_shadow.h: the skip in front
+                                     // of the exact test)
   int32_t view_valid;
   int32_t keep_bins;                 // the render kernel leaves the bin counters alone (SRH_STAGE_KEEP_BINS, light views)
   SegDev seg[SRH_MAX_SEGMENTS];

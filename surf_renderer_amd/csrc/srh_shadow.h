@@ -16,9 +16,12 @@
 //                           and primitives within near_ball of the light go to the frame-wide lists, because the
 //                           reference accepts occluders up to 0.1 behind the light (ts < |L - p| from an origin 0.1 in)
 //   k_shadow_shade_binned   per hit pixel and light: the ray's image point -> its tile -> the tile's candidates (and
-//                           the frame-wide lists; a ray outside the view can meet only those) -> the SAME fp64 test
-//                           against the SAME primary-pass records as the all-pairs kernel -> nearest blocker,
-//                           lowest index on ties.  Then the pixel is shaded again with the visibility bits.
+//                           the frame-wide lists; a ray outside the view can meet only those), minus those no point of
+//                           which is close enough to the light to lie between it and the fragment (FrameDev::neardist)
+//                           -> the SAME fp64 test against the SAME primary-pass records as the all-pairs kernel, until
+//                           one candidate other than the pixel's own primitive blocks the light in front of the
+//                           pixel's own hit (lowest index on ties).  Then the pixel is shaded again with the
+//                           visibility bits.
 //
 // A candidate list is a superset of the primitives the ray meets (the stored shapes are inflated, the bins padded), and
 // every candidate goes through the exact test, so visibility bits and image equal the all-pairs pass bit for bit.
@@ -56,43 +59,66 @@ __global__ void k_bounds_init(int* bounds) {
   else if (threadIdx.x < 9) bounds[threadIdx.x] = 0;
 }
 
+// Grid-stride over the batch, one set of atomics per WORKGROUP (waves combine through LDS): with one set per wave of a
+// thread-per-primitive grid the 100 k discs of BASELINE config 5 queued 12 k atomics on eight addresses -- 146 us.
+constexpr int kBoundsBlocks = 64;
 __global__ __launch_bounds__(256) void k_scene_bounds(FrameDev F, int s, int* bounds) {
   const SegDev& S = F.seg[s];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  bool bad = false;
-  float size = 0.0f, one = 0.0f;
-  if (i < S.count && S.type != SRH_PRIM_PLANE) {
+  bool any_bad = false;
+  float size = 0.0f, count = 0.0f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.count && S.type != SRH_PRIM_PLANE; i += gridDim.x * blockDim.x) {
+    float plo[3], phi[3], psize;
+    bool bad = false;
     if (S.type == SRH_PRIM_TRIANGLE) {
       const float* f = S.face + 12 * (size_t)i;
+      for (int k = 0; k < 3; ++k) { plo[k] = 3.0e38f; phi[k] = -3.0e38f; }
       for (int v = 0; v < 3; ++v)
-        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], f[4 * v + k]); hi[k] = fmaxf(hi[k], f[4 * v + k]); bad |= !isfinite(f[4 * v + k]); }
-      size = 0.5f * fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        for (int k = 0; k < 3; ++k) { plo[k] = fminf(plo[k], f[4 * v + k]); phi[k] = fmaxf(phi[k], f[4 * v + k]); bad |= !isfinite(f[4 * v + k]); }
+      psize = 0.5f * fmaxf(fmaxf(phi[0] - plo[0], phi[1] - plo[1]), phi[2] - plo[2]);
     } else {
       const float* c = S.pos + 4 * (size_t)i;
       const float r = fabsf(S.radius[i]);
-      for (int k = 0; k < 3; ++k) { lo[k] = c[k] - r; hi[k] = c[k] + r; bad |= !isfinite(lo[k]) || !isfinite(hi[k]); }
-      size = r;
+      for (int k = 0; k < 3; ++k) { plo[k] = c[k] - r; phi[k] = c[k] + r; bad |= !isfinite(plo[k]) || !isfinite(phi[k]); }
+      psize = r;
     }
-    one = 1.0f;
+    if (bad) { any_bad = true; continue; }
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], plo[k]); hi[k] = fmaxf(hi[k], phi[k]); }
+    if (isfinite(psize)) { size += psize; count += 1.0f; }
   }
-  if (__builtin_amdgcn_ballot_w64(bad)) { if ((threadIdx.x & 63) == 0) bounds[6] = 1; }
-  if (bad) { size = 0.0f; one = 0.0f; }
+  // wave, then workgroup
+  __shared__ float red[4][8];
+  __shared__ int red_bad[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { size += __shfl_xor(size, m); one += __shfl_xor(one, m); }
-  if ((threadIdx.x & 63) == 0 && one > 0.0f && isfinite(size)) {
-    atomicAdd(reinterpret_cast<float*>(bounds + 7), size);
-    atomicAdd(bounds + 8, (int)one);
+  for (int m = 32; m >= 1; m >>= 1) {
+    size += __shfl_xor(size, m);
+    count += __shfl_xor(count, m);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], m)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m)); }
   }
-  if (bad) return;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float a = lo[k], b = hi[k];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { a = fminf(a, __shfl_xor(a, m)); b = fmaxf(b, __shfl_xor(b, m)); }
-    if ((threadIdx.x & 63) == 0) {
-      if (a < 3.0e38f) atomicMin(&bounds[k], ordered_int(a));
-      if (b > -3.0e38f) atomicMax(&bounds[3 + k], ordered_int(b));
+  const bool wave_bad = __builtin_amdgcn_ballot_w64(any_bad) != 0ull;
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) { red[wave][k] = lo[k]; red[wave][3 + k] = hi[k]; }
+    red[wave][6] = size; red[wave][7] = count;
+    red_bad[wave] = wave_bad ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool bad = false;
+    for (int w = 1; w < 4; ++w) {
+      for (int k = 0; k < 3; ++k) { red[0][k] = fminf(red[0][k], red[w][k]); red[0][3 + k] = fmaxf(red[0][3 + k], red[w][3 + k]); }
+      red[0][6] += red[w][6]; red[0][7] += red[w][7];
+    }
+    for (int w = 0; w < 4; ++w) bad |= red_bad[w] != 0;
+    if (bad) bounds[6] = 1;
+    if (red[0][7] > 0.0f && isfinite(red[0][6])) {
+      atomicAdd(reinterpret_cast<float*>(bounds + 7), red[0][6]);
+      atomicAdd(bounds + 8, (int)red[0][7]);
+    }
+    for (int k = 0; k < 3; ++k) {
+      if (red[0][k] < 3.0e38f) atomicMin(&bounds[k], ordered_int(red[0][k]));
+      if (red[0][3 + k] > -3.0e38f) atomicMax(&bounds[3 + k], ordered_int(red[0][3 + k]));
     }
   }
 }
@@ -106,6 +132,7 @@ __global__ void k_light_frames(FrameDev T, const float* __restrict__ lpos, int n
   FrameDev F = T;
   const size_t by = (size_t)l * slice_bytes;
   F.tilerange = (uint16_t*)((char*)F.tilerange + by);
+  F.neardist = (float*)((char*)F.neardist + by);
   F.counters = (uint32_t*)((char*)F.counters + by);
   F.large = (uint32_t*)((char*)F.large + by);
   F.entries = (uint32_t*)((char*)F.entries + by);
@@ -181,53 +208,6 @@ __device__ __forceinline__ bool light_image_point(const FrameDev& LF, const doub
   return true;
 }
 
-// Can the BINNED primitive whose light-view reject record this is block the shadow ray that leaves the light through
-// the image point (c, r)?  Two proofs of "no", the ones the primary pass uses per pixel (srh_reject.h), evaluated here
-// in fp64 on the stored fp32 coefficients at a continuous position (the records' margins cover positions between
-// pixel centres: they are stated in pixels, and a bin's rectangle is already grown by bin_pad for the same reason):
-//   shape   the ray's line misses the inflated ellipse / lies outside an inflated triangle edge;
-//   depth   the record's inverse-depth bound puts every hit on the ray's line farther from the light than
-//           `reach` = |L - fragment| - 0.1, where a blocker cannot be (it must lie between the ray's origin, 0.1 in
-//           front of the fragment, and the light); a plane provably behind the light (den <= hi_u) cannot block
-//           either -- primitives within 0.1 of the light never come here: they are on the frame-wide lists.
-// Candidates that pass go through the exact fp64 test as before, so the result does not change.
-// MEASURED AND NOT ADOPTED (-DSRH_SHADOW_PRETEST): every lane walks its own list, so the reject record is one more
-// scattered 48-byte fetch per entry in front of the 64-byte exact record, and the test itself is no cheaper than the
-// exact one it saves: shadow pass of config 5 3.9 -> 5.4 ms, 20 k discs at 512^2 0.31 -> 0.38 ms.
-__device__ __forceinline__ bool shadow_candidate(int type, const float* __restrict__ rec, double c, double r, double len,
-                                                 double reach) {
-  double den = 0.0, hi = 0.0;
-  bool planar = true;
-  if (type == SRH_PRIM_DISK || type == SRH_PRIM_SPHERE) {
-    const double dc = c - (double)rec[0], dr = r - (double)rec[1];
-    const double q = dc * ((double)rec[2] * dc + (double)rec[3] * dr) + (double)rec[4] * dr * dr - 1.0;
-    if (q > 1.0e-6) return false;
-    if (type == SRH_PRIM_SPHERE) {
-      planar = false;
-      const double inv = rec[5];                                       // >= 1 / t for every hit on the sphere; 1e30: none
-      if (inv < 1.0e29 && inv * reach * 1.000001 < 1.0) return false;
-    } else {
-      den = (double)rec[5] + c * (double)rec[6] + r * (double)rec[7];
-      hi = rec[10];
-    }
-  } else if (type == SRH_PRIM_TRIANGLE) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if ((double)rec[4 * i] * c + (double)rec[4 * i + 1] * r + (double)rec[4 * i + 2] < -1.0e-6) return false;
-    den = (double)rec[3] + c * (double)rec[7] + r * (double)rec[11];
-    hi = rec[14];
-  } else {
-    den = (double)rec[0] + c * (double)rec[1] + r * (double)rec[2];
-    hi = rec[5];
-  }
-  if (planar) {
-    if (den <= hi) return false;                                       // behind the light on this ray
-    // den / len >= 1 / t: the hit is at least len / den from the light
-    if (den < 1.0e29 && den * reach * 1.000001 < len) return false;
-  }
-  return true;
-}
-
 __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const FrameDev* __restrict__ LFs,
                                                               float* __restrict__ image, const float* __restrict__ depth,
                                                               const int32_t* __restrict__ nearest,
@@ -271,20 +251,30 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
     const double dist = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
     const double dir[3] = {v[0] / dist, v[1] / dist, v[2] / dist};
     const double q[3] = {(p[0] + 0.1 * dir[0]) - F.o[0], (p[1] + 0.1 * dir[1]) - F.o[1], (p[2] + 0.1 * dir[2]) - F.o[2]};
-    double tmin = __builtin_inf();
-    int blocker = -1;
-    auto test = [&](int sg, int g) {
+    auto hit = [&](int sg, int g) {
       const SegDev& B = F.seg[sg];
-      const double ts = hit_any64_from(B.type, B.rec64 + (size_t)(g - B.first) * kRec64Stride[B.type], F.o, q, dir);
-      if (ts > 0.0 && ts < dist && (ts < tmin || (ts == tmin && g < blocker))) { tmin = ts; blocker = g; }
+      return hit_any64_from(B.type, B.rec64 + (size_t)(g - B.first) * kRec64Stride[B.type], F.o, q, dir);
     };
-    const double reach = dist - 0.1;                      // a blocker lies closer to the light than this
-    (void)reach;
+    // The reference lights the pixel iff the nearest blocker (lowest index on ties) is the pixel's own primitive, or
+    // there is none (torch/renderer.py:306-314).  So the own primitive is tested first, and the light is blocked iff
+    // some OTHER primitive's hit comes lexicographically before (ts_self, win) -- the walk stops at the first such
+    // candidate instead of looking for the nearest one.
+    double ts_self = __builtin_inf();
+    {
+      const double ts = hit(sw, win);
+      if (ts > 0.0 && ts < dist) ts_self = ts;
+    }
+    bool blocked = false;
+    auto test = [&](int sg, int g) {
+      if (g == win) return;
+      const double ts = hit(sg, g);
+      if (ts > 0.0 && ts < dist && (ts < ts_self || (ts == ts_self && g < win))) blocked = true;
+    };
     const FrameDev& LF = LFs[l];
     if (!LF.view_valid || !isfinite(dist)) {
       // no usable light view: every primitive, as the all-pairs pass does
       for (int sg = 0; sg < F.nseg; ++sg)
-        for (int i = 0; i < F.seg[sg].count; ++i) test(sg, F.seg[sg].first + i);
+        for (int i = 0; i < F.seg[sg].count && !blocked; ++i) test(sg, F.seg[sg].first + i);
     } else {
       // where the ray leaves the light: direction from the light towards the fragment
       const double w[3] = {-dir[0], -dir[1], -dir[2]};
@@ -292,28 +282,48 @@ __global__ __launch_bounds__(256) void k_shadow_shade_binned(FrameDev F, const F
       const bool front = light_image_point(LF, w, lc, lr, llen);
       const bool inside = front && lc >= 0.0 && lr >= 0.0 && lc <= (double)(LF.W - 1) && lr <= (double)(LF.H - 1);
       const int tile = inside ? ((int)lr / kTile) * LF.tiles_x + (int)lc / kTile : 0;
+      // A valid blocker's hit point lies between the ray's origin (0.1 in front of the fragment) and 0.1 beyond the
+      // light: closer to the light than max(dist - 0.1, 0.1).  A candidate no point of which is that close
+      // (FrameDev::neardist, a lower bound rounded down; `reach` rounded up) cannot block: it is skipped before its
+      // 64-byte record is fetched.  Primitives within 0.1 of the light never come here (frame-wide lists).
+      const float reach = (float)fmax(dist - 0.1, 0.1) * 1.000001f;
+      const float* __restrict__ nd = LF.neardist;
       for (int sg = 0; sg < F.nseg; ++sg) {
         const uint32_t* big = LF.large + LF.seg[sg].first;
         const uint32_t nbig = large_length(LF, sg);
-        for (uint32_t i = 0; i < nbig; ++i) test(sg, (int)big[i]);
-        if (inside) {
+        for (uint32_t i = 0; i < nbig && !blocked; ++i) test(sg, (int)big[i]);
+        if (inside && !blocked) {
           const int bin = sg * LF.ntiles_pad + tile;
           const uint32_t* list = bin_list(LF, bin);
-          const uint32_t nlist = bin_length(LF, bin);
-          const SegDev& LS = LF.seg[sg];
-          const int stride = rec32_stride(LS.type);
-          (void)stride;
-          for (uint32_t i = 0; i < nlist; ++i) {
-            const int g = (int)list[i];
-#ifdef SRH_SHADOW_PRETEST      // measured and dropped: config 5 3.9 -> 5.4 ms (a second scattered record per entry)
-            if (!shadow_candidate(LS.type, LS.rec32 + (size_t)(g - LS.first) * stride, lc, lr, llen, reach)) continue;
-#endif
-            test(sg, g);
+          uint32_t nlist = bin_length(LF, bin);
+          // Two phases per round, so that the lanes of a wave (each on its own list) run the expensive exact test
+          // together: every lane first skips ahead to its next surviving candidates -- four list entries and their four
+          // distances per step, so that a step costs two memory round trips, not eight -- then all lanes that found one
+          // test it.
+          uint32_t base = 0, mask = 0;
+          int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+          for (;;) {
+            while (mask == 0u && base < nlist) {
+              const uint32_t last = nlist - 1;
+              c0 = (int)list[base];
+              c1 = (int)list[min(base + 1, last)];
+              c2 = (int)list[min(base + 2, last)];
+              c3 = (int)list[min(base + 3, last)];
+              const float n0 = nd[c0], n1 = nd[c1], n2 = nd[c2], n3 = nd[c3];
+              mask = (n0 < reach ? 1u : 0u) | ((base + 1 < nlist && n1 < reach) ? 2u : 0u) |
+                     ((base + 2 < nlist && n2 < reach) ? 4u : 0u) | ((base + 3 < nlist && n3 < reach) ? 8u : 0u);
+              base += 4;
+            }
+            if (mask == 0u) break;
+            const int k = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            test(sg, k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3);
+            if (blocked) break;
           }
         }
       }
     }
-    if (blocker < 0 || blocker == win) vis |= 1ull << l;
+    if (!blocked) vis |= 1ull << l;
   }
   float rgb[3];
   shade_pixel_t<true>(F, d, t, win, rgb, nullptr, nullptr, org, vis);
