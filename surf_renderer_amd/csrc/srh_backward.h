@@ -27,6 +27,17 @@ struct GradsDev {
   float* ambient;       // torch shading only
 };
 
+// gamma * x^(gamma - 1) for x > 0, the tonemap's derivative, the way tonemap_f32 evaluates the tonemap itself: hardware
+// log2 / exp2 in fp32 (1.1e-6 relative while |(gamma - 1) log2 x| <= 12; the gradients leave as fp32 sums and are checked
+// to 2e-4 of their largest entry), the fp64 library pow outside that range.  The library call is ~250 fp64
+// instructions per channel: a third of the numpy-shading backward kernel.
+__device__ __forceinline__ double tonemap_slope(double x, double gamma) {
+  const float xf = (float)x, e = (float)(gamma - 1.0);
+  const float y = e * __builtin_amdgcn_logf(xf);
+  if (xf >= 1.0e-30f && xf <= 1.0e30f && fabsf(y) <= 12.0f) return gamma * (double)__builtin_amdgcn_exp2f(y);
+  return gamma * pow(x, gamma - 1.0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -83,7 +94,7 @@ __device__ __forceinline__ void scatter_primitive_grads(const GradsDev& G, int k
   v[6] = run.reduce((float)g_r);
   // Second level, for primitives larger than a wave's 64 pixels: when each of the workgroup's four waves (four image
   // rows) is ONE run of the same primitive, wave 0 adds the four sums and issues the only atomics of the workgroup.
-  // (All 256 threads reach this barrier: the backward kernels have no early exit.)
+  // (All 256 threads reach this barrier: a workgroup leaves the backward kernels only as a whole, at their top.)
   __shared__ float wsum[4][8];
   __shared__ int wkey[4];
   const int wave = threadIdx.y;
@@ -133,6 +144,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
   const int cc = live ? c : 0;
   // background pixels (depth = +inf) and pixels outside the slab take part in the wave reductions with zeros
   const bool hit = live && isfinite(depth[row * F.depth_stride + cc]);
+  // a workgroup (4 rows x 64 pixels) without a single hit pixel contributes nothing: it leaves together, before the
+  // reductions below (whose barriers every thread of a workgroup that stays still reaches) -- a mesh that covers a fifth
+  // of the frame then runs a fifth of the workgroups through the fp64 chain rule
+  if (!__syncthreads_or(hit ? 1 : 0)) return;
 
   double g_out[3] = {0, 0, 0}, g_dep = 0.0;
   int win = 0;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
     const float* lp = F.lpos + 4 * l;
     const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
     const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
-    const double inv = (len2 > 0.0) ? 1.0 / sqrt(len2) : 1.0;
+    const double inv = (len2 > 0.0) ? rsqrt_newton(len2) : 1.0;     // ~1e-15 relative: far inside the fp32 sums
     const double sdot = ((n[0] * v[0] + n[1] * v[1]) + n[2] * v[2]) * inv;
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
 #pragma unroll
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
   for (int ch = 0; ch < 3; ++ch) {
     double w = 0.0;
     if (hit) {
-      if (F.tonemap) w = (im[ch] > 0.0) ? F.gamma * pow(im[ch], F.gamma - 1.0) : 0.0;
+      if (F.tonemap) w = (im[ch] > 0.0) ? tonemap_slope(im[ch], F.gamma) : 0.0;
       else w = (im[ch] >= 0.0) ? 1.0 : 0.0;
     }
     g_im[ch] = g_out[ch] * w;
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(FrameDev F, GradsDev G, cons
     const double v[3] = {(double)lp[0] - p[0], (double)lp[1] - p[1], (double)lp[2] - p[2]};
     const double len2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
     const bool nz = len2 > 0.0;
-    const double inv = nz ? 1.0 / sqrt(len2) : 1.0;
+    const double inv = nz ? rsqrt_newton(len2) : 1.0;
     const double lh[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
     const double sdot = (n[0] * lh[0] + n[1] * lh[1]) + n[2] * lh[2];
     const int ci = clampi(F.lcidx[l], 0, F.ncolors - 1);
@@ -357,6 +372,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SRH_BWD_TCH
   const size_t row = live ? (size_t)(r - F.row0) : 0;
   const int cc = live ? c : 0;
   const bool hit = live && ((double)depth[row * F.depth_stride + cc] <= F.far_clip);
+  // a workgroup (4 rows x 64 pixels) without a single hit pixel contributes nothing: it leaves together, before the
+  // reductions below (whose barriers every thread of a workgroup that stays still reaches) -- a mesh that covers a fifth
+  // of the frame then runs a fifth of the workgroups through the fp64 chain rule
+  if (!__syncthreads_or(hit ? 1 : 0)) return;
 
   float g_out[3] = {0, 0, 0}, g_dep = 0.0f;               // upstream gradients are fp32
   int win = 0;
