@@ -597,8 +597,9 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   const size_t ntiles = ((size_t)L.tiles_x * L.tiles_y_max + 3) / 4 * 4;
   L.tilerange = off;
   off = align_up(off + total * 4 * sizeof(uint16_t));
-  L.neardist = off;                                // light views only (FrameDev::neardist)
-  off = align_up(off + total * sizeof(float));
+#ifdef SRH_WS_SHIFT      // measurement build: extra bytes in front of the counters / lists (the layout moves the frame time)
+  off = align_up(off + (size_t)(SRH_WS_SHIFT));
+#endif
   L.counters = off;
   L.counters_bytes = (kCounterPad + SRH_MAX_SEGMENTS * ntiles) * sizeof(uint32_t);
   off = align_up(off + L.counters_bytes);
@@ -608,6 +609,8 @@ WsLayout layout_for(const SrhObjects* ob, int width, int height) {
   // one-pass binning: every bin owns entries_words / nbins slots (at least kMinBinCap of them)
   L.entries_words = std::max(total * kMaxTilesPerPrim, (size_t)SRH_MAX_SEGMENTS * ntiles * kMinBinCap);
   off = align_up(off + L.entries_words * sizeof(uint32_t));
+  L.neardist = off;                                // light views only (FrameDev::neardist); last, so that the regions a
+  off = align_up(off + total * sizeof(float));     // primary frame touches keep their places
   L.total = off;
   return L;
 }
