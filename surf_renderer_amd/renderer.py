@@ -175,6 +175,9 @@ def flatten_scene(scene: Dict[str, Any], device="cuda", validate: bool = True, k
     ``keep_graph`` keeps tensors that require grad attached to autograd (see ``render``)."""
     device = torch.device(device)
     _require_gpu(device)
+    if device.type == "cuda" and device.index is None:
+        # "cuda" means the current device; tensors report "cuda:N", and the out-buffer checks compare devices
+        device = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.load()
     objs = scene["objects"]
     if not objs:

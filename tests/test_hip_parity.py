@@ -751,3 +751,21 @@ def test_views_with_their_own_geometry_lights_and_shadows(shading, shadow):
             assert torch.equal(got["visibility"][v], one["light_visibility"]), f"view {v}: visibility"
     assert not torch.equal(got["image"][0], got["image"][1])
 
+
+
+def test_bare_cuda_device_means_the_current_device():
+    """flatten_scene(device="cuda") -- torch reports tensors on "cuda:N", and every out-buffer check compares devices: a
+    scene flattened on the bare name used to refuse its own preallocated outputs (renderer.bin_statistics raised)."""
+    from surf_renderer_amd import renderer, synthetic
+    scene = synthetic.disk_cloud_scene(500, 96, 64)
+    buf = renderer.flatten_scene(scene, device="cuda")
+    assert buf.device.index == torch.cuda.current_device()
+    cam = renderer.camera_struct(scene["camera"])
+    st = renderer.bin_statistics(buf, cam)
+    assert st["executed_pair_tests"] > 0
+    image = torch.empty((64, 96, 3), dtype=torch.float32, device="cuda")
+    depth = torch.empty((64, 96), dtype=torch.float32, device="cuda")
+    renderer.render_buffers(buf, cam, out=(image, depth, None))
+    ref = renderer.render(scene, device="cuda:0")
+    torch.cuda.synchronize()
+    assert torch.equal(image, ref["image"]) and torch.equal(depth, ref["depth"])

@@ -20,7 +20,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN3srh15k_render_binnedILb0ELi1ELi0EEEvNS_8FrameDevEPfS2_Pi"
+KERNEL = "_ZN3srh19k_render_binned_memILb0ELi1ELi0EEEvPU3AS4KNS_8FrameDevEPfS4_Pi"
 CHEAP = re.compile(r"^v_(add_f32|sub_f32|subrev_f32|mul_f32|and_b32|or_b32|xor_b32|not_b32|ashrrev_i32|lshlrev_b32|lshrrev_b32|"
                    r"add_u32|sub_u32|subrev_u32|mov_b32|add_co_u32|addc_co_u32)(_e32)?$")
 TRANS32 = re.compile(r"^v_(rcp|rsq|sqrt|log|exp|sin|cos)_(f32|iflag_f32)")
