@@ -919,7 +919,8 @@ def main():
                        "parallelism": (f"frames/{world}" if frames_par else f"rows/{world}") if not args.as_rank
                                       else f"rehearsal of rank {args.as_rank}",
                        "launches": ("one srh_render_views call per batch of frames"
-                                    if batched and not owner and args.batch_call != "off" else "per frame"),
+                                    if batched and args.batch_call != "off" and (not owner or cost_parts is not None)
+                                    else "per frame"),
                        "rows_per_rank": (f"work-balanced contiguous slabs (bin lengths of a probe frame): "
                                          f"{[b_ - a for a, b_ in cost_parts]} rows" if cost_parts is not None else
                                          f"owner-weighted: the rank that assembles a frame renders {max(recv_rows)} of "
