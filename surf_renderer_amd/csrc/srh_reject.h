@@ -385,24 +385,37 @@ __device__ inline BBox conic_bbox(const float* rec) {
 }
 
 // Box of the triangle cut out by the three stored (inflated) edge half-planes, if it is bounded.
+// Three half-planes a_i c + b_i r + g_i >= 0 with unit normals bound a region iff the normals turn the same way round
+// from each to the next (all three cross products of one sign): otherwise some direction leaves none of them, and the
+// region is a wedge, a strip or a half-plane.  The latter is what a huge triangle seen from near its plane looks like:
+// its far edges all project onto the plane's HORIZON, three nearly identical lines -- whose pairwise "intersections"
+// are rounding noise that used to pass for a tiny triangle somewhere off the image, and the primitive was then not
+// binned at all (found by the adversarial campaign, seed 3505 scene 2238; tests/test_hip_adversarial.py).  Cross
+// products below 1e-5 are refused too: a corner is (g_i n_j - g_j n_i) / D with |g| up to 1e9 pixels.
 __device__ inline BBox triangle_bbox(const float* rec) {
   double a[3], b[3], g[3];
   for (int i = 0; i < 3; ++i) {
     a[i] = rec[4 * i]; b[i] = rec[4 * i + 1]; g[i] = rec[4 * i + 2];
     if (a[i] == 0.0 && b[i] == 0.0) return bbox_full();
   }
+  const double D01 = a[0] * b[1] - a[1] * b[0], D12 = a[1] * b[2] - a[2] * b[1], D20 = a[2] * b[0] - a[0] * b[2];
+  const bool ccw = D01 > 1.0e-5 && D12 > 1.0e-5 && D20 > 1.0e-5, cw = D01 < -1.0e-5 && D12 < -1.0e-5 && D20 < -1.0e-5;
+  if (!ccw && !cw) return bbox_full();
   double cmin = 1e300, cmax = -1e300, rmin = 1e300, rmax = -1e300;
   for (int i = 0; i < 3; ++i) {
     const int j = (i + 1) % 3, k = (i + 2) % 3;
     const double D = a[i] * b[j] - a[j] * b[i];
-    if (!(fabs(D) > 1e-9)) return bbox_full();
     const double c = (-g[i] * b[j] + g[j] * b[i]) / D;
     const double r = (-a[i] * g[j] + a[j] * g[i]) / D;
     if (!isfinite(c) || !isfinite(r)) return bbox_full();
     if (!(a[k] * c + b[k] * r + g[k] >= -1e-6 * (fabs(c) + fabs(r) + fabs(g[k]) + 1.0))) return bbox_full();
     cmin = fmin(cmin, c); cmax = fmax(cmax, c); rmin = fmin(rmin, r); rmax = fmax(rmax, r);
   }
-  return BBox{cmin - 1.0, cmax + 1.0, rmin - 1.0, rmax + 1.0, false};
+  // the corners carry the rounding of the division: 2^-52 (|g_i| + |g_j|) / |D| pixels, far below the pixel of slack
+  // for |g| < 1e9 and |D| > 1e-5 only if |g| stays below ~1e6 -- beyond that the slack grows with it
+  const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  const double slack = 1.0 + 1.0e-10 * gmax;
+  return BBox{cmin - slack, cmax + slack, rmin - slack, rmax + slack, false};
 }
 
 // Can a pixel of the rectangle [c0,c1] x [r0,r1] (inclusive pixel coordinates) be a valid hit of the primitive whose

@@ -87,3 +87,38 @@ def test_huge_primitives_that_cross_the_view(kind):
     # measured on the MI355X (seed 31000): disc 0, plane 0, triangle 2e-4, sphere 2e-3 of the pixels
     assert off <= 0.01 * total, f"{kind}: {off} of {total} pixels differ from the oracle"
     print(f"{kind}: {n} scenes, {covered} with hits, {off} of {total} pixels off the oracle (all won by huge primitives)")
+
+
+def test_huge_triangle_seen_along_its_horizon():
+    """A triangle with vertices 2^30 away whose plane passes close to the eye: its far edges all project onto the
+    plane's horizon -- three nearly identical lines in the image.  The binning's box of "the triangle the three stored
+    edges cut out" took the rounding noise of their pairwise intersections for a tiny triangle off the image and left the
+    primitive out of every bin: the binned modes lost it on all 5764 pixels it wins (adversarial campaign seed 3505,
+    scene 2238, found on the round-3 library; the all-pairs `fast` mode was right).  Now such edges mean "no box"."""
+    f32 = lambda a: np.asarray(a, dtype=np.float32)                       # noqa: E731
+    scene = {
+        "camera": {"proj_type": "perspective", "viewport": [0, 0, 96, 64], "fovy": 1.2217304763960306, "focal_length": 1.0,
+                   "eye": [0.051125227195726264, 4.862591237619495, -3.514625537232991, 1.0],
+                   "at": [-0.2827726690421051, -0.025735496740256967, 0.113589653655605, 1.0],
+                   "up": [-0.47260978736042225, -0.923752417083577, 1.4991403301183073, 0.0], "near": 1.0, "far": 1e30},
+        "lights": {"pos": f32([[3, 4, 5, 1], [-4, 2, 3, 1]]), "color_idx": np.array([1, 2])},
+        "colors": f32([[0, 0, 0], [.8, .5, .4], [.3, .6, .9]]),
+        "materials": {"albedo": f32([[.5, .5, .5], [.9, .3, .2], [.2, .7, .4]])},
+        "tonemap": {"type": "gamma", "gamma": 0.8},
+        "objects": {
+            "triangle": {
+                "face": f32([[[-536870912.0, -1073741824.0, -1073741824.0, 1.0], [1073741824.0, 0.25610265135765076, 0.25610265135765076, 1.0],
+                              [-1073741824.0, 1073741824.0, 1073741824.0, 1.0]],
+                             [[-0.5016877055168152, -1.517171859741211, 0.001920813345350325, 1.0], [-0.8127182126045227, -1.1657752990722656, -0.19767971336841583, 1.0],
+                              [-1.0391697883605957, -0.6801849007606506, -0.4513838291168213, 1.0]],
+                             [[0.6122082471847534, -0.6791490316390991, -1.0723912715911865, 1.0], [-0.5048546195030212, -0.851209282875061, -0.5838438868522644, 1.0],
+                              [-0.10402628034353256, -0.8538187146186829, -0.1468411386013031, 1.0]]]),
+                "normal": f32([[-0.0, -1.0, 1.0, 0.0], [0.007773317396640778, -0.03370987996459007, -0.07145911455154419, 0.0],
+                               [0.0739159882068634, -0.6839831471443176, -0.07188151031732559, 0.0]]),
+                "material_idx": np.array([2, 1, 0])},
+            "sphere": {"pos": f32([[0.08068179339170456, -0.19134069979190826, -0.9597193002700806, 1.0],
+                                   [0.7705283164978027, -0.1693117767572403, -0.47138261795043945, 1.0]]),
+                       "radius": f32([0.17742614448070526, 0.1269519329071045]), "material_idx": np.array([2, 1])}},
+    }
+    ref, _ = check_scene(scene, "horizon triangle")
+    assert (ref["nearest"] == 0).sum() > 5000 and np.isfinite(ref["depth"]).sum() > 5000      # the huge triangle fills the view
