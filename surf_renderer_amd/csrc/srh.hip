@@ -144,12 +144,20 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
     // query tests it
     bool near_eye = false;
     if (F.near_ball > 0.0) {
-      double dmin = 0.0;
+      // distance from the light to the nearest point the primitive can have, as a difference of two lengths -- which
+      // cancels for a primitive as large as it is far (centre 1e20 away, radius 1e20): 2^-46 of the lengths' sum,
+      // 64x their rounding, comes off
+      double dmin = 0.0, mag = 0.0;
       if (TYPE == SRH_PRIM_DISK) {
         const double oc[3] = {F.o[0] - R[4], F.o[1] - R[5], F.o[2] - R[6]};
-        dmin = sqrt(dot3(oc, oc)) - sqrt(fabs(R[7]));
+        const double dc = sqrt(dot3(oc, oc)), rr = sqrt(fabs(R[7]));
+        dmin = dc - rr; mag = dc + rr;
       }
-      else if (TYPE == SRH_PRIM_SPHERE) dmin = sqrt(dot3(R, R)) - sqrt(fabs(dot3(R, R) - R[3]));
+      else if (TYPE == SRH_PRIM_SPHERE) {
+        // (the radius itself: |oc|^2 - (|oc|^2 - r^2) gives r^2 back only to 2^-52 |oc|^2)
+        const double dc = sqrt(dot3(R, R)), rr = fabs((double)S.radius[i]);
+        dmin = dc - rr; mag = dc + rr;
+      }
       else if (TYPE == SRH_PRIM_TRIANGLE) {
         double far2 = 0.0, near2 = 1.0e300;
 #pragma unroll
@@ -160,7 +168,9 @@ __device__ __forceinline__ void prep_body(const FrameDev& F, int s, double* rec6
           far2 = fmax(far2, dot3(e, e));
         }
         dmin = sqrt(near2) - sqrt(far2);                        // every point is within one edge length of a vertex
+        mag = sqrt(near2) + sqrt(far2);
       }
+      dmin -= 1.4210854715202004e-14 * mag;
       near_eye = !(dmin > F.near_ball);                         // NaN -> large
       // what the shadow pass skips candidates by: no point of the primitive is closer to the light than this (rounded
       // DOWN to fp32; 0 = unknown: planes, non-finite geometry)

@@ -37,7 +37,7 @@ def main():
                          "2^30..2^66 that cross the view), all four kinds in turn, with the checks of "
                          "tests/test_hip_adversarial.py")
     args = ap.parse_args()
-    if args.adversarial:
+    if args.adversarial and not args.shadows:
         from adversarial_scenes import KINDS, huge_scene
         import test_hip_adversarial as A
         rng = np.random.RandomState(args.seed)
@@ -104,8 +104,10 @@ def main():
     if args.shadows:
         import test_hip_torch_shading as TS
         n_shadowed = 0
+        if args.adversarial:                   # --shadows --adversarial: the directed huge-primitive scenes as occluders
+            from adversarial_scenes import KINDS, huge_scene
         while time.time() - t0 < args.seconds:
-            sc = T._random_scene(rng)
+            sc = huge_scene(rng, KINDS[it % 4]) if args.adversarial else T._random_scene(rng)
             sc["camera"]["near"] = max(sc["camera"]["near"], 0.01)
             n_l = int(rng.randint(1, 5))
             lp = rng.normal(size=(n_l, 3))
