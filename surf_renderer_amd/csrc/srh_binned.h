@@ -234,6 +234,7 @@ constexpr int kKeys = SRH_KEYS;             // keys tracked per pixel: kKeys - 1
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct QuadState {
+  uint32_t ordmask;   // wave-uniform: the low key bits that hold the list position (ord_mask_for), <= kOrdMask
   f32x2 cf[2];        // pixel columns as fp32 (exact integers): (c, c+1), (c+2, c+3)
   float rf;           // pixel row
   f32x2 rlen[2];      // 1 / |D| of the un-normalised ray direction
@@ -248,23 +249,26 @@ __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
   return r;
 }
 
-// (bits(inv) & ~kOrdMask) | field in one v_bfi_b32 (field <= kOrdMask, in a vector register)
-#ifndef SRH_FIELD_SGPR
-#define SRH_FIELD_SGPR 0
-#endif
-__device__ __forceinline__ int32_t pack_key(float inv, uint32_t field) {
+// The key's position field is as wide as THIS tile's lists need, not a fixed 12 bits: a tile with n entries uses
+// b = bits(n + 1) low bits (mask 2^b - 1 >= n + 1, so no field saturates), at most kOrdMask's 12.  Every bit the field does
+// not take stays with the inverse-depth bound: at BASELINE config 5 (41 entries per busy tile on average, 103 at most)
+// the bound keeps 16-17 mantissa bits instead of 11, and two candidates have to be 32-64 times closer in depth before
+// the finish has to confirm both.  With 12 fixed bits the second confirmation ran in 4 of 10 finish rounds (one
+// ambiguous pixel among a round's 64 is enough); it is ~60 fp64 instructions for the whole wave.
+__device__ __forceinline__ uint32_t ord_mask_for(uint32_t n_entries) {
+  const uint32_t bits = 32u - (uint32_t)__builtin_clz(n_entries + 1u);        // n_entries + 1 >= 1
+  return min((1u << bits) - 1u, kOrdMask);
+}
+
+// (bits(inv) & ~mask) | field in one v_bfi_b32 (field <= mask, in a vector register; `keep` = ~mask, wave-uniform)
+__device__ __forceinline__ int32_t pack_key(float inv, uint32_t field, uint32_t keep) {
   int32_t r;
-#if SRH_FIELD_SGPR   // measurement build: the (wave-uniform) field as the instruction's scalar operand, the mask in a register
-  const uint32_t maskv = 0xFFFFF000u;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(maskv), "v"(inv), "s"(field));
-#else
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFF000u), "v"(inv), "v"(field));
-#endif
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(keep), "v"(inv), "v"(field));
   return r;
 }
 
-__device__ __forceinline__ bool key_saturated(int32_t key) { return ((uint32_t)key & kOrdMask) == kOrdMask; }
-__device__ __forceinline__ uint32_t key_ordinal(int32_t key) { return ((uint32_t)key & kOrdMask) - 1u; }
+__device__ __forceinline__ bool key_saturated(int32_t key, uint32_t mask) { return ((uint32_t)key & mask) == mask; }
+__device__ __forceinline__ uint32_t key_ordinal(int32_t key, uint32_t mask) { return ((uint32_t)key & mask) - 1u; }
 
 // fp32 LOWER bound of the ray distance a key stands for (rcp is good to 1 ulp; the factor covers it)
 // Does a candidate whose inverse-depth bound is `inv` (>= 1 / t of any valid hit of it) still "reach" a pixel whose
@@ -276,7 +280,7 @@ __device__ __forceinline__ uint32_t key_ordinal(int32_t key) { return ((uint32_t
 // unless the hit is closer than 1e-25, where it reaches anyway.  bound = +inf (nothing confirmed) gives reach 0.
 constexpr float kReachMax = 1.0e25f;
 __device__ __forceinline__ float reach_of(float bound) { return fminf(__builtin_amdgcn_rcpf(bound) * 0.999999f, kReachMax); }
-__device__ __forceinline__ float key_inv(int32_t key) { return __uint_as_float((uint32_t)key | kOrdMask); }   // >= 1 / t
+__device__ __forceinline__ float key_inv(int32_t key, uint32_t mask) { return __uint_as_float((uint32_t)key | mask); }   // >= 1 / t
 
 // fp32 value that is certainly >= the fp64 depth (the conversion may round down by half an ulp)
 __device__ __forceinline__ float float_above(double t) { return (float)t * 1.0000005f; }
@@ -469,9 +473,10 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
   int32_t sel[4];
   f32x2 inv[2];
   pair_bounds<TYPE, PRETEST, !DENKEYS>(R, Q.cf, Q.rf, Q.rlen, sel, inv);
+  const uint32_t keep = ~Q.ordmask;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int32_t key = pack_key(inv[j >> 1][j & 1], field) & sel[j];
+    const int32_t key = pack_key(inv[j >> 1][j & 1], field, keep) & sel[j];
     if (kKeys == 4) Q.k4[j] = imed3(Q.k3[j], key, Q.k4[j]);
     Q.k3[j] = imed3(Q.k2[j], key, Q.k3[j]);
     Q.k2[j] = imed3(Q.k1[j], key, Q.k2[j]);
@@ -486,7 +491,7 @@ __device__ __forceinline__ void sweep_entry(const RejectRecord<TYPE>& R, uint32_
 // wait for B comes only after A's ~100 vector instructions.  No register copies between the buffers.
 template <int TYPE, int WPT, class Op>
 __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
-                                            uint32_t ord0, uint32_t part, Op&& op) {
+                                            uint32_t ord0, uint32_t part, Op&& op, uint32_t ordmask = kOrdMask) {
   // with WPT waves per tile this wave takes entries part, part + WPT, ...;  op(record, global index, key field)
   if (n_all <= part) return;
   const uint32_t n = (n_all - part + WPT - 1) / WPT;
@@ -501,7 +506,7 @@ __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __r
   auto record = [&](int g) {
     return reinterpret_cast<const float*>(base_c + (uint32_t)g * (uint32_t)(4 * kRec32Stride[TYPE]));
   };
-  auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, kOrdMask); };
+  auto field = [&](uint32_t k) { return min(ord0 + k * WPT + part + 1, ordmask); };
   int gA = entry(0);
   int gB = entry(1);
   A.load(record(gA));
@@ -532,7 +537,7 @@ __device__ __forceinline__ void stream_list(const SegDev& S, const uint32_t* __r
 #endif
 template <int TYPE, int WPT, class Op>
 __device__ __forceinline__ void stream_list_vec(const SegDev& S, const uint32_t* __restrict__ list, uint32_t n_all,
-                                                uint32_t ord0, uint32_t part, int lane, Op&& op) {
+                                                uint32_t ord0, uint32_t part, int lane, Op&& op, uint32_t ordmask = kOrdMask) {
   if (n_all <= part) return;
   constexpr int kQuads = kRec32Stride[TYPE] / 4;
   const uint32_t n = (n_all - part + WPT - 1) / WPT;
@@ -561,7 +566,7 @@ __device__ __forceinline__ void stream_list_vec(const SegDev& S, const uint32_t*
         A.v[4 * q + 2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].z), (int)e));
         A.v[4 * q + 3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur[q].w), (int)e));
       }
-      op(A, 0, min(ord0 + (c0 + e) * WPT + part + 1, kOrdMask));
+      op(A, 0, min(ord0 + (c0 + e) * WPT + part + 1, ordmask));
     }
     if (more) {
 #pragma unroll
@@ -576,11 +581,11 @@ __device__ __forceinline__ void sweep_list(const SegDev& S, const uint32_t* __re
 #if SRH_SWEEP_VEC
   stream_list_vec<TYPE, WPT>(S, list, n_all, ord0, part, lane, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
     sweep_entry<TYPE, PRETEST, DENKEYS>(R, field, Q);
-  });
+  }, Q.ordmask);
 #else
   stream_list<TYPE, WPT>(S, list, n_all, ord0, part, [&](const RejectRecord<TYPE>& R, int, uint32_t field) {
     sweep_entry<TYPE, PRETEST, DENKEYS>(R, field, Q);
-  });
+  }, Q.ordmask);
 #endif
 }
 
@@ -927,14 +932,18 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
   uint32_t has = 0;                           // bit j: pixel j of the quad exists, is mine and has a candidate
   // a tile nobody reaches (every list empty; the same for all waves of a workgroup that shares the tile) goes straight
   // to the background stores: no ray set-up, no sweep
-  uint32_t listed = 0;
+  uint32_t listed = 0;                        // entries of the tile's lists, all batches
   {
     const TileLists L{F, tile};
-    for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) listed |= L.count(s, 0) | L.count(s, 1);
+    for (int s = 0; s < ((BATCH >= 0) ? 1 : F.nseg); ++s) listed += L.count(s, 0) + L.count(s, 1);
   }
+  // low key bits that hold a candidate's list position (ord_mask_for); the matrix-core measurement build packs its
+  // keys with the full 12 bits, so it keeps them everywhere
+  const uint32_t ordmask = SRH_MFMA ? kOrdMask : ord_mask_for(listed);
   if (listed) {
     const int r = min(r_raw, F.row1 - 1);
     QuadState Q;
+    Q.ordmask = ordmask;
     Q.rf = (float)r;
     // |D|^2 of the quad's four pixels: D(c0 + j) = D(c0) + j Dc, so |D|^2 = A + j (B + j C) with A = |D(c0)|^2,
     // B = 2 D(c0).Dc, C = |Dc|^2 -- one fp64 ray instead of four (equal to ~1e-16 relative; only the fp32 bound uses it)
@@ -1061,7 +1070,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       front[wave][j][lane] =
-          (((has >> j) & 1u) && !key_saturated(Q.k1[j])) ? ordinal_to_global<BATCH>(F, tile, key_ordinal(Q.k1[j])) : -1;
+          (((has >> j) & 1u) && !key_saturated(Q.k1[j], ordmask)) ? ordinal_to_global<BATCH>(F, tile, key_ordinal(Q.k1[j], ordmask)) : -1;
     }
   }
 
@@ -1153,11 +1162,11 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
 #pragma unroll
         for (int q = 0; q < kKeys - 1; ++q) {
           const int32_t key = keys[q];
-          if (key != kNoKey && !saturated && key_inv(key) >= reach) {
-            if (key_saturated(key)) {
+          if (key != kNoKey && !saturated && key_inv(key, ordmask) >= reach) {
+            if (key_saturated(key, ordmask)) {
               saturated = true;
             } else {
-              const int g = (q == 0) ? gfront : ordinal_to_global<BATCH>(F, tile, key_ordinal(key));
+              const int g = (q == 0) ? gfront : ordinal_to_global<BATCH>(F, tile, key_ordinal(key, ordmask));
               if (q == 0) g1 = g;
               if (q == 1) g2 = g;
               if (q == 0) resolve_lex(F, fr.hit(F, d), g, best, besti);
@@ -1168,7 +1177,7 @@ __device__ __forceinline__ void render_binned_body(const FrameDev& __restrict__ 
           }
         }
         // the fourth key is only a bound: if it still reaches the confirmed depth, somebody unknown might too
-        slow = saturated || (sentinel != kNoKey && key_inv(sentinel) >= reach);
+        slow = saturated || (sentinel != kNoKey && key_inv(sentinel, ordmask) >= reach);
         if (slow) { g1 = g2 = -1; }           // the slow path re-confirms; cheaper than excluding three indices
       }
 #endif

@@ -45,7 +45,21 @@ def main():
         it = off = total = 0
         while time.time() - t0 < args.seconds:
             kind = KINDS[it % 4]
-            ref, bad = A.check_scene(huge_scene(rng, kind), f"{kind} seed {args.seed} scene {it}")
+            sc = huge_scene(rng, kind)
+            ref, bad = A.check_scene(sc, f"{kind} seed {args.seed} scene {it}")
+            # the same scene as a row slab (the multi-GPU partition: its bounding-ball pre-cull runs only there) and
+            # under the torch backend's semantics, binned against all pairs
+            H = sc["camera"]["viewport"][3]
+            r0 = int(rng.randint(0, H - 1))
+            r1 = int(rng.randint(r0 + 1, H + 1))
+            slab = A._render(sc, rows=(r0, r1))
+            tb, te = A._render(sc, mode="binned", shading="torch"), A._render(sc, mode="exact", shading="torch")
+            for what, got, want in (("rows", slab, {k: ref[k][r0:r1] for k in ref}), ("torch shading", tb, te)):
+                for k in ("nearest", "depth", "image"):
+                    ne = ~((got[k] == want[k]) | (np.isnan(got[k]) & np.isnan(want[k])))
+                    if ne.any():
+                        print(f"FAIL {kind} seed {args.seed} scene {it} ({what} {r0}:{r1}): {k} differs on {ne.sum()} values", flush=True)
+                        sys.exit(1)
             off += bad
             total += ref["depth"].size
             it += 1
