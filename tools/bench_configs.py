@@ -32,8 +32,16 @@ def forward_rate(name, scene, steps=50):
     out = (torch.empty((h, w, 3), device="cuda:0"), torch.empty((h, w), device="cuda:0"),
            torch.empty((h, w), dtype=torch.int32, device="cuda:0"))
     dt = timed(lambda: renderer.render_buffers(buf, cam, out=out), steps)
+    # the same frames through the pipeline bench.py uses: three in flight on three streams, one hipGraph each
+    from surf_renderer_amd.pipeline import FramePipeline
+    pipe = FramePipeline(buf, cam, n_inflight=3, graphs=True)
+    dp = timed(pipe.submit, 20 * steps, 50)
+    pipe.verify()
     print(json.dumps({"config": name, "width": w, "height": h, "prims": buf.total, "ms_per_frame": 1e3 * dt,
-                      "frames_per_s": 1 / dt, "gtests_per_s": buf.total * w * h / dt / 1e9}), flush=True)
+                      "frames_per_s": 1 / dt, "gtests_per_s": buf.total * w * h / dt / 1e9,
+                      "ms_per_frame_pipelined": 1e3 * dp, "frames_per_s_pipelined": 1 / dp,
+                      "what": "ms_per_frame: one eager srh_render_fwd call after another on one stream (a frame's latency); "
+                              "pipelined: three frames in flight, graph replays, checked bit for bit"}), flush=True)
 
 
 def main():
