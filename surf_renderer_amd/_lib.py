@@ -100,6 +100,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         if not build_if_missing:
             raise RuntimeError(f"{path} is missing; run `python -m surf_renderer_amd.build`")
         _build.build_lib()
+    # torch first: the device buffers this library is handed come from torch's HIP runtime, and the process must hold
+    # ONE runtime -- dlopening libsrh.so before torch pulls in the system's libamdhip64, torch then brings its own, and
+    # every launch ends in "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process)
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):
