@@ -57,7 +57,13 @@
   X(39, "v_min_f32 %0, %0, %1", "v_min_f32 (VOP2)", x, fa)                          \
   X(40, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0xe0", "v_bitop3_b32", u, v1)          \
   X(41, "v_writelane_b32 %0, s20, 3", "v_writelane_b32", u, v1)                    \
-  X(42, "v_mov_b64 %0, %1", "v_mov_b64", d, da)
+  X(42, "v_mov_b64 %0, %1", "v_mov_b64", d, da)                                    \
+  X(43, "v_mul_lo_u32 %0, %0, %1", "v_mul_lo_u32", u, v1)                          \
+  X(44, "v_mul_u32_u24 %0, %0, %1", "v_mul_u32_u24 (VOP2)", u, v1)                 \
+  X(45, "v_mad_u32_u24 %0, %0, %1, %1", "v_mad_u32_u24 (VOP3)", u, v1)             \
+  X(46, "v_mad_u64_u32 %0, s[22:23], %1, %1, %0", "v_mad_u64_u32", d, v1)          \
+  X(47, "v_lshl_add_u64 %0, %0, 2, %0", "v_lshl_add_u64", d, da)                   \
+  X(48, "v_add3_u32 %0, %0, %1, %1", "v_add3_u32", u, v1)
 
 constexpr int kIters = 1500;
 constexpr int kPerIter = 32;
