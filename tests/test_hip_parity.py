@@ -769,3 +769,35 @@ def test_bare_cuda_device_means_the_current_device():
     ref = renderer.render(scene, device="cuda:0")
     torch.cuda.synchronize()
     assert torch.equal(image, ref["image"]) and torch.equal(depth, ref["depth"])
+
+
+def test_key_field_width_follows_the_tile_list_length():
+    """The packed keys give the list position bits(n + 1) low bits for a tile with n entries (srh_binned.h:
+    ord_mask_for), at most 12 -- so n just below, at and above every power of two up to the saturation point must all
+    resolve like the all-pairs mode: n coincident-in-screen discs over ONE tile, depths a few 1e-4 apart so that
+    neighbouring keys differ only in the bits the field width decides about, plus ties (equal depths: lowest index)."""
+    rng = np.random.RandomState(77)
+    for n in (1, 2, 3, 6, 7, 8, 14, 15, 16, 30, 31, 32, 62, 63, 64, 126, 127, 128, 254, 255, 256, 510, 511, 512,
+              1022, 1023, 1024, 2046, 2047, 2048, 4093, 4094, 4095, 4096, 4200):
+        pos = np.zeros((n, 4), dtype=np.float32)
+        pos[:, 0] = rng.uniform(-0.01, 0.01, n)
+        pos[:, 1] = rng.uniform(-0.01, 0.01, n)
+        z = rng.uniform(-0.2, 0.2, n)
+        z[rng.randint(0, n, max(1, n // 3))] = z[0]                     # ties with disc 0
+        z += rng.randint(-2, 3, n) * 1e-4                               # near ties
+        pos[:, 2] = z
+        pos[:, 3] = 1.0
+        nrm = np.zeros((n, 4), dtype=np.float32)
+        nrm[:, :3] = rng.normal(size=(n, 3)) * 0.15 + np.array([0.0, 0.0, 1.0])
+        scene = {
+            "camera": {"proj_type": "perspective", "viewport": [0, 0, 32, 16], "fovy": 0.3, "focal_length": 1.0,
+                       "eye": [0.0, 0.0, 4.0, 1.0], "up": [0.0, 1.0, 0.0, 0.0], "at": [0.0, 0.0, 0.0, 1.0], "near": 0.1, "far": 100.0},
+            "lights": {"pos": np.array([[3, 4, 5, 1]], dtype=np.float32), "color_idx": np.array([1])},
+            "colors": np.array([[0, 0, 0], [.8, .7, .6]], dtype=np.float32),
+            "materials": {"albedo": np.array([[.6, .6, .6]], dtype=np.float32)},
+            "tonemap": {"type": "gamma", "gamma": 0.8},
+            "objects": {"disk": {"pos": pos, "normal": nrm, "radius": rng.uniform(0.1, 0.5, n).astype(np.float32),
+                                 "material_idx": np.zeros(n, dtype=np.int64)}},
+        }
+        ref = _modes_identical(scene, modes=("exact", "binned"))
+        assert np.isfinite(ref["depth"]).any(), n
