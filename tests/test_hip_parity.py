@@ -571,8 +571,16 @@ def test_fuzz_non_finite_and_degenerate_primitives():
         W, H = scene["camera"]["viewport"][2:]
         if W * H <= 64 * 80 and sum(len(g["material_idx"]) for g in scene["objects"].values()) <= 800:
             with np.errstate(all="ignore"):
-                want = np_oracle.render(scene_to_numpy(scene, round_fp32=True))
+                # dots="ordered": the reference's np.dot contractions as explicit sums in the order the GPU path
+                # documents.  A poisoned primitive (a vertex at -inf beside a normal component of 1e20, say) can leave a
+                # pixel hanging on the last bit of such a sum, and the BLAS behind np.dot rounds it in an order of its
+                # own (seed 2203, scene 2109: one pixel, the two oracle variants disagree with EACH OTHER there) -- so
+                # the BLAS variant may differ from the GPU only where it differs from the ordered one
+                want = np_oracle.render(scene_to_numpy(scene, round_fp32=True), dots="ordered")
+                blas = np_oracle.render(scene_to_numpy(scene, round_fp32=True))
                 np.testing.assert_array_equal(ref["nearest"], want["nearest"])
+                split = blas["nearest"] != want["nearest"]
+                assert ((ref["nearest"] == blas["nearest"]) | split).all() and split.mean() < 0.01
                 d = ref["depth"].astype(np.float64)
                 assert np.all(np.isclose(d, want["depth"], rtol=DEPTH_RTOL, atol=0) | (d == want["depth"]))
                 img = ref["image"].astype(np.float64)
